@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- SA neighbour-cost evaluations per second on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N=1: plain python; N>1: torchrun)
+
+One "step" = one pass of the hot path over one batch: K_nb candidate neighbours of the
+current slab generated and costed exactly, one accept decision, base structures refreshed.
+Workload at every N = BASELINE configs[1]: enwik5-shaped 100 000 B (synthetic, seeded --
+no corpora exist offline), 4 096 neighbours/step, lc=lp=pb=0, top-K 20.  One chain per GPU
+with its own RNG stream (weak scaling); the path has no data-path collective except the
+per-epoch best-slab exchange (one 8-byte RCCL all-reduce + a broadcast), done once inside
+the timed region.
+
+Rank 0 prints ONE JSON line.  `value` = neighbour evaluations that produced a cost, summed
+over all ranks, / max-over-ranks wall time of the K timed steps (inputs resident in HBM
+before the timed region).  `roofline` prices the dominant kernel (k_neighbours) with
+SURVEY section 8d's algorithmic bytes B_eval = N + 12*P per evaluation against 8 TB/s, using
+that kernel's average duration from HIP events recorded on the library's own stream.
+`cpu_baseline` times the compiled reference (oracle/_ref, kind "reference") or else the CPU
+oracle (kind "port") on a bounded sample of the same workload, 1 thread, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(data, seconds):
+    """Reference-semantics SA iterations (main.c:78-102) on one host thread."""
+    import _libs
+
+    n = len(data)
+    if _libs.Ref.available():
+        eng, kind, seed_fn = _libs.Ref(data), "reference", _libs.Ref.lib().ref_srand
+    else:
+        eng, kind, seed_fn = _libs.Oracle(data), "port", _libs.Oracle.lib().orc_srand
+    slab, best = _libs.literal_slab(n), _libs.literal_slab(n)
+    seed_fn(1673551)
+    cur = bst = 0
+    done, chunk = 0, 100
+    t0 = time.perf_counter()
+    while True:
+        r = eng.sa_iters(slab, best, cur, bst, 0, n, done, done + chunk)
+        cur, bst = r["cur"], r["best"]
+        done += chunk
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 40000:
+            break
+    return dict(value=done / el, unit="evals/s", cores=1, kind=kind,
+                sample=f"{done} SA iterations (seed 1673551, from the all-literal slab) of the same "
+                       f"{n} B input in {el:.1f} s on 1 thread")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--size", type=int, default=0, help="override the input size (bytes)")
+    ap.add_argument("--neighbours", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+
+    from megalania_amd import binding, corpus, multi_gpu
+
+    data, desc = corpus.config_input(args.config, args.size or None)
+    n = len(data)
+    K = args.neighbours or {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}[args.config]
+    props = dict(pb=2) if args.config == "c5" else {}
+    sa = binding.SA(data, neighbours_per_step=K, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=n,
+                    device=local_rank, timing=True, **props)
+
+    def sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    sa.run(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    st = sa.run(args.steps)
+    if dist is not None:
+        import torch
+        multi_gpu.exchange_best(sa, dist, device=torch.device("cuda", local_rank))
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    evals, walked = st["evaluations"], st["packets_evaluated"]
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed, float(evals), float(walked)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, evals, walked = float(tmax[0]), float(t[1]), float(t[2])
+
+    if rank == 0:
+        # dominant kernel: k_neighbours.  Algorithmic bytes per evaluation:
+        # B_eval = N + 12 * P  (every input byte once + one 12-byte packet record per packet)
+        P = st["packets"]
+        b_eval = n + 12 * P
+        launches = max(1, st["neighbour_launches"])
+        avg_ms = st["gpu_ms_neighbours"] / launches
+        evals_per_launch = st["evaluations"] / max(1, st["steps"])
+        achieved = evals_per_launch * b_eval / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "SA neighbour-cost evals/s",
+            "value": evals / elapsed,
+            "unit": "evals/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {desc}, {n} B, {K} neighbours/step, top-K 20, "
+                                   f"lc/lp/pb={props.get('lc', 0)}/{props.get('lp', 0)}/{props.get('pb', 0)}",
+                       "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_neighbours", "avg_launch_ms": avg_ms, "launches_timed": launches,
+                         "b_eval_bytes": b_eval, "packets_on_walk": P,
+                         "bytes_walked_per_eval": (walked / max(1.0, evals)) * 8 + n * (walked / max(1.0, evals)) / max(1, P)},
+            "final": {"current_cost": st["current_cost"], "best_cost": st["best_cost"],
+                      "est_bytes_best": 18 + st["best_cost"] / 16384, "accepted": st["accepted"],
+                      "gpu_ms_rebuild_avg": st["gpu_ms_rebuild"] / launches,
+                      "gpu_ms_total": st["gpu_ms_total"]},
+        }
+        if n_gpus == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(data, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    sa.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/*
+ * megalania_hip.h -- C ABI of the MI355X SA hot path (libmegalania_hip.so).
+ *
+ * Drop-in boundary for blackle/Megalania's simulated-annealing loop.  Everything here is
+ * plain C: pointers, sizes, integer status codes.  The library owns all device memory; the
+ * caller owns every host buffer it passes in.  One host thread per mgl_sa handle (the
+ * reference is single-threaded: global rand(), stateful TopKPacketFinder).
+ *
+ * What each entry point replaces in the reference (paths relative to its src/):
+ *
+ *   mgl_sa_create     main.c:44-51   lzma_state_init + packet_enumerator_new (match index,
+ *                                    substring_enumerator.c:26-47) + top_k_packet_finder_new(20)
+ *                                    + packet_slab_new (all-literal, packet_slab.c:15-35)
+ *   mgl_sa_begin_epoch main.c:69-77  fresh slab per epoch (all-literal, or a copy of best)
+ *   mgl_sa_run        main.c:78-102  the hot loop: packet_slab_neighbour_generate
+ *                                    (packet_slab_neighbour.c:154-173: prefix cost, mutate,
+ *                                    top-K pick, repair, total perplexity), accept / undo
+ *   mgl_sa_best       main.c:91      packets_best, handed back in the reference's own
+ *                                    12-byte LZMAPacket layout (lzma_packet.h:13-17) so that
+ *                                    main.c:110-119 (header + range coder) emits it unchanged
+ *   mgl_cost_slab     the loop of main.c:116-118 run with perplexity_encoder
+ *                                    (perplexity_encoder.c:6-17) instead of range_encoder
+ *   mgl_top_k         top_k_packet_finder_find/pop (top_k_packet_finder.c:120-138)
+ *   mgl_substrings    substring_enumerator_for_each (substring_enumerator.c:85-105)
+ *   mgl_sa_destroy    main.c:107-108,121 the matching frees
+ *
+ * Error convention: the reference returns NULL / -1 / false and prints to stderr
+ * (packet_slab.c:18-27, memory_mapper.c:12-31); here constructors return NULL and
+ * operations return 0 or a negative MGL_E* code; mgl_last_error() has the text.
+ * Nothing aborts; HIP errors are translated.
+ */
+#ifndef MEGALANIA_HIP_H
+#define MEGALANIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGL_OK 0
+#define MGL_EINVAL (-1)   /* bad argument */
+#define MGL_ENOMEM (-2)   /* host or device allocation failed */
+#define MGL_EDEVICE (-3)  /* HIP runtime error (no GPU, launch failure, ...) */
+#define MGL_ERANGE (-4)   /* position not on the slab's walk / buffer too small */
+
+/* lzma_packet.h:5-17 -- identical layout (type @0, dist @4, len @8, sizeof == 12). */
+#ifndef MGL_NO_PACKET_TYPES
+typedef struct {
+	uint8_t type;   /* 1 LITERAL, 2 MATCH, 3 SHORT_REP, 4 LONG_REP */
+	uint32_t dist;  /* MATCH: distance-1; LONG_REP: rep index 0..3 */
+	uint16_t len;   /* LITERAL/SHORT_REP: 1; else 2..273 */
+} mgl_packet;
+/* lzma_state.h:53-57 */
+typedef struct {
+	uint8_t lc, lp, pb;
+} mgl_properties;
+#endif
+
+typedef struct {
+	uint64_t seed;                /* main.c:68 uses 1673551 */
+	uint32_t neighbours_per_step; /* K: candidate neighbours costed per SA step */
+	uint32_t top_k;               /* main.c:49 uses 20; at most 32 */
+	uint32_t dict_limit;          /* candidates need dist < dict_limit; 0 = 0x400000, the
+	                                 dictionary size lzma_header_encoder.c:16 writes */
+	uint32_t max_bucket_scan;     /* cap on match-index hits scanned per top-K query, nearest
+	                                 first; 0 = unlimited (the reference's behaviour) */
+	uint64_t iters_per_epoch;     /* main.c:67 num_iters (defaults to the input size) */
+	int32_t device;               /* HIP device ordinal */
+	uint32_t flags;               /* MGL_F_* */
+} mgl_sa_config;
+
+#define MGL_F_TIMING 1u /* record HIP events around every kernel launch of mgl_sa_run */
+
+typedef struct {
+	uint64_t steps;          /* SA steps executed by this call */
+	uint64_t evaluations;    /* neighbour evaluations that produced a cost (successful generates) */
+	uint64_t failed;         /* generates that found no candidate (main.c:81-84 retries those) */
+	uint64_t accepted;       /* steps that moved to a neighbour */
+	uint64_t improved;       /* steps that set a new best */
+	uint64_t current_cost;   /* perplexity of the current slab, 1/2048-bit units; 0 = none yet */
+	uint64_t best_cost;
+	uint64_t packets;        /* packets on the current slab's walk */
+	uint64_t packets_evaluated; /* sum over evaluations of the packets costed (for B_eval) */
+	double gpu_ms_total;     /* first launch -> last launch, HIP events on the library's stream */
+	double gpu_ms_neighbours;/* sum over launches of the neighbour kernel (MGL_F_TIMING) */
+	double gpu_ms_rebuild;   /* sum over launches of the base rebuild kernel (MGL_F_TIMING) */
+	uint64_t neighbour_launches;
+} mgl_sa_stats;
+
+typedef struct {
+	uint32_t position;
+	mgl_packet old_packet;
+	mgl_packet new_packet;
+} mgl_diff;
+
+typedef struct mgl_sa mgl_sa;
+
+/* library / device */
+const char* mgl_version(void);
+const char* mgl_last_error(void);
+int mgl_device_count(void);
+
+/* lifecycle.  `data` is copied to the device; it is not retained. */
+mgl_sa* mgl_sa_create(const uint8_t* data, size_t n, mgl_properties props, const mgl_sa_config* cfg);
+void mgl_sa_destroy(mgl_sa* sa);
+
+/* Start an epoch (main.c:71-77): phase = the reference's `step` (0..2); from_best != 0 copies
+ * the best slab into the current one, else the current slab becomes all-literal.  Resets the
+ * within-epoch iteration counter and the current cost. */
+int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best);
+/* Replace the current slab (n entries, position-indexed).  Must be a valid parse. */
+int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets);
+/* Adopt a best slab found elsewhere (another chain / GPU): replaces best slab and best cost.
+ * `perplexity` must be the slab's exact cost (it is re-derived on the device and checked). */
+int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t perplexity);
+/* Run `steps` SA steps, each costing cfg.neighbours_per_step neighbours.  Entirely
+ * device-resident; the call returns after the last kernel has completed. */
+int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats);
+/* Current / best slab, n entries each, reference layout. */
+int mgl_sa_current(mgl_sa* sa, mgl_packet* packets_out, uint64_t* perplexity_out);
+int mgl_sa_best(mgl_sa* sa, mgl_packet* packets_out, uint64_t* perplexity_out);
+
+/* Parity hooks (each leaves the SA state untouched). */
+/* Cost a whole slab from byte 0.  per_packet_cumulative (nullable) receives one running
+ * total per walked packet; npackets (nullable) their number. */
+int mgl_cost_slab(mgl_sa* sa, const mgl_packet* packets, uint64_t* total,
+                  uint64_t* per_packet_cumulative, size_t* npackets);
+/* Final model state after costing `packets`: probabilities in the reference's struct order
+ * (lzma_state.h:47-53: lit | len | rep_len | dist | ctx_state), ctx_state, rep distances. */
+int mgl_final_state(mgl_sa* sa, const mgl_packet* packets, uint16_t* probs_out, size_t probs_cap,
+                    uint8_t* ctx_state_out, uint32_t dists_out[4]);
+/* Best cfg.top_k next packets at `position` (must be on the walk of `packets`), in the
+ * reference's pop order: worst first, best last.  costs[i] = perplexity/length (integer). */
+int mgl_top_k(mgl_sa* sa, const mgl_packet* packets, size_t position, mgl_packet* out,
+              uint64_t* costs, size_t* count);
+/* Match-index query at `pos`: (offset, length) pairs in the reference's callback order. */
+int mgl_substrings(mgl_sa* sa, size_t pos, size_t max_len, uint32_t* offsets, uint32_t* lengths,
+                   size_t cap, size_t* count);
+/* Generate and cost the K neighbours the *next* mgl_sa_run step would look at (or those of
+ * an explicit global step number), without deciding.  costs[j] = UINT64_MAX for a failed
+ * generate.  diffs (nullable): diff_cap entries per neighbour, ndiffs[j] valid ones. */
+int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* diffs,
+                   uint32_t* ndiffs, size_t diff_cap);
+/* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the
+ * step's own stream (accept decision). */
+uint32_t mgl_rng_draw_at(uint64_t seed, uint64_t step, uint32_t j, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGALANIA_HIP_H */

@@ -1,0 +1,547 @@
+/*
+ * mgl_api.hip -- the C ABI of include/megalania_hip.h over the kernels in mgl_kernels.hip.
+ * Owns all device memory; one HIP stream per handle; no host thread is created.
+ */
+#include "mgl_kernels.hip"
+#include "../../include/megalania_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+static const uint16_t k_cost_table[2048] = {
+#include "mgl_cost_table.inc"
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg)
+{
+	g_err = msg;
+	return code;
+}
+#define HIPCHK(expr)                                                                         \
+	do {                                                                                     \
+		hipError_t e_ = (expr);                                                              \
+		if (e_ != hipSuccess)                                                                \
+			return fail(MGL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+	} while (0)
+
+extern "C" const char* mgl_version(void) { return "megalania-hip 0.1 (gfx950)"; }
+extern "C" const char* mgl_last_error(void) { return g_err.c_str(); }
+extern "C" int mgl_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+extern "C" uint32_t mgl_rng_draw_at(uint64_t seed, uint64_t step, uint32_t j, uint32_t n)
+{
+	return mgl_rng_draw(mgl_rng_key(seed, step, j), n);
+}
+
+struct BaseMem {
+	BaseView v;
+	Control* ctl;
+};
+
+struct mgl_sa {
+	int device;
+	hipStream_t stream;
+	uint32_t n;
+	mgl_properties props;
+	mgl_sa_config cfg;
+	DevCtx ctx;
+	uint8_t* d_data;
+	uint32_t* d_bucket_off;
+	uint32_t* d_bucket_pos;
+	uint16_t* d_cost_tbl;
+	BaseMem base, scratch;
+	mgl_pk* d_best;
+	NbrOut nbr;
+	uint32_t* d_aos;
+	uint64_t* d_cum;
+	uint16_t* d_final_probs;
+	mgl_pk* d_topk_pk;
+	uint64_t* d_topk_cost;
+	uint32_t* d_small; /* [0] count */
+	uint32_t* d_sub_offs;
+	uint32_t* d_sub_lens;
+	uint32_t sub_cap;
+	uint64_t sqrt_thresh;
+	uint32_t per_wave_bytes, waves_per_block, nbr_lds, walk_lds;
+	hipEvent_t ev_begin, ev_end;
+	std::vector<hipEvent_t> ev_pool;
+};
+
+static uint64_t ceil_sqrt_u64(uint64_t x)
+{
+	uint64_t r = (uint64_t)sqrt((double)x);
+	while (r * r > x) r--;
+	while ((r + 1) * (r + 1) <= x) r++;
+	return r * r == x ? r : r + 1;
+}
+
+static void dfree(void* p) { if (p) (void)hipFree(p); }
+static void free_base(BaseMem& b)
+{
+	dfree(b.v.slab); dfree(b.v.onwalk); dfree(b.v.ckpt_probs); dfree(b.v.ckpt_hdr); dfree(b.ctl);
+	memset(&b, 0, sizeof b);
+}
+static hipError_t alloc_base(BaseMem& b, uint32_t n, uint32_t ckpt_elems)
+{
+	memset(&b, 0, sizeof b);
+	hipError_t e;
+	b.v.nckpt = (n + (1u << MGL_CKPT_SHIFT) - 1u) >> MGL_CKPT_SHIFT;
+	b.v.ckpt_elems = ckpt_elems;
+	if ((e = hipMalloc(&b.v.slab, sizeof(mgl_pk) * (size_t)n)) != hipSuccess) return e;
+	if ((e = hipMalloc(&b.v.onwalk, sizeof(uint64_t) * (((size_t)n + 63) / 64 + 1))) != hipSuccess) return e;
+	if ((e = hipMalloc(&b.v.ckpt_probs, sizeof(uint16_t) * (size_t)b.v.nckpt * ckpt_elems)) != hipSuccess) return e;
+	if ((e = hipMalloc(&b.v.ckpt_hdr, sizeof(CkptHdr) * (size_t)b.v.nckpt)) != hipSuccess) return e;
+	if ((e = hipMalloc(&b.ctl, sizeof(Control))) != hipSuccess) return e;
+	if ((e = hipMemset(b.v.onwalk, 0, sizeof(uint64_t) * (((size_t)n + 63) / 64 + 1))) != hipSuccess) return e;
+	return hipMemset(b.ctl, 0, sizeof(Control));
+}
+
+static int launch_rebuild(mgl_sa* sa, BaseMem& b, int from_dirty, uint64_t* cum, uint16_t* final_probs)
+{
+	hipLaunchKernelGGL(k_rebuild, dim3(1), dim3(64), sa->walk_lds, sa->stream, sa->ctx, b.v, b.ctl, from_dirty, cum, final_probs);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
+static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
+{
+	const uint32_t K = sa->cfg.neighbours_per_step;
+	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
+	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
+	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
+
+static int import_slab(mgl_sa* sa, const mgl_packet* packets, mgl_pk* d_slab)
+{
+	HIPCHK(hipMemcpyAsync(sa->d_aos, packets, sizeof(mgl_packet) * (size_t)sa->n, hipMemcpyHostToDevice, sa->stream));
+	hipLaunchKernelGGL(k_import, dim3(1024), dim3(256), 0, sa->stream, (const uint32_t*)sa->d_aos, d_slab, sa->n);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
+static int export_slab(mgl_sa* sa, const mgl_pk* d_slab, mgl_packet* packets)
+{
+	hipLaunchKernelGGL(k_export, dim3(1024), dim3(256), 0, sa->stream, d_slab, sa->d_aos, sa->n);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(packets, sa->d_aos, sizeof(mgl_packet) * (size_t)sa->n, hipMemcpyDeviceToHost, sa->stream));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	return MGL_OK;
+}
+
+extern "C" void mgl_sa_destroy(mgl_sa* sa)
+{
+	if (!sa) return;
+	(void)hipSetDevice(sa->device);
+	if (sa->stream) (void)hipStreamSynchronize(sa->stream);
+	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_cost_tbl);
+	free_base(sa->base); free_base(sa->scratch);
+	dfree(sa->d_best);
+	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
+	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
+	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
+	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
+	for (hipEvent_t e : sa->ev_pool) (void)hipEventDestroy(e);
+	if (sa->ev_begin) (void)hipEventDestroy(sa->ev_begin);
+	if (sa->ev_end) (void)hipEventDestroy(sa->ev_end);
+	if (sa->stream) (void)hipStreamDestroy(sa->stream);
+	delete sa;
+}
+
+static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
+{
+	HIPCHK(hipSetDevice(sa->device));
+	HIPCHK(hipStreamCreate(&sa->stream));
+	HIPCHK(hipEventCreate(&sa->ev_begin));
+	HIPCHK(hipEventCreate(&sa->ev_end));
+	const mgl_layout L = mgl_make_layout(sa->props.lc, sa->props.lp, sa->props.pb);
+	const uint32_t ckpt_elems = (L.total + 7u) & ~7u;
+
+	/* input, zero padded so that window loads past the end stay in bounds */
+	HIPCHK(hipMalloc(&sa->d_data, n + 128));
+	HIPCHK(hipMemset(sa->d_data, 0, n + 128));
+	HIPCHK(hipMemcpy(sa->d_data, data, n, hipMemcpyHostToDevice));
+
+	/* match index (substring_enumerator.c:26-47): positions bucketed by leading bigram,
+	 * ascending inside a bucket.  Setup work, built once on the host. */
+	{
+		std::vector<uint32_t> off(65537, 0), posv(n ? n : 1, 0);
+		for (size_t i = 1; i < n; i++) off[(((uint32_t)data[i - 1] << 8) | data[i]) + 1]++;
+		for (uint32_t b = 0; b < 65536; b++) off[b + 1] += off[b];
+		std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+		for (size_t i = 1; i < n; i++) posv[fill[((uint32_t)data[i - 1] << 8) | data[i]]++] = (uint32_t)(i - 1);
+		HIPCHK(hipMalloc(&sa->d_bucket_off, sizeof(uint32_t) * 65537));
+		HIPCHK(hipMalloc(&sa->d_bucket_pos, sizeof(uint32_t) * posv.size()));
+		HIPCHK(hipMemcpy(sa->d_bucket_off, off.data(), sizeof(uint32_t) * 65537, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(sa->d_bucket_pos, posv.data(), sizeof(uint32_t) * posv.size(), hipMemcpyHostToDevice));
+	}
+	HIPCHK(hipMalloc(&sa->d_cost_tbl, sizeof(k_cost_table)));
+	HIPCHK(hipMemcpy(sa->d_cost_tbl, k_cost_table, sizeof(k_cost_table), hipMemcpyHostToDevice));
+
+	sa->ctx.data = sa->d_data; sa->ctx.n = (uint32_t)n;
+	sa->ctx.bucket_off = sa->d_bucket_off; sa->ctx.bucket_pos = sa->d_bucket_pos;
+	sa->ctx.cost_tbl = sa->d_cost_tbl; sa->ctx.L = L;
+	sa->ctx.dict_limit = sa->cfg.dict_limit; sa->ctx.max_scan = sa->cfg.max_bucket_scan; sa->ctx.top_k = sa->cfg.top_k;
+
+	HIPCHK(alloc_base(sa->base, (uint32_t)n, ckpt_elems));
+	HIPCHK(alloc_base(sa->scratch, (uint32_t)n, ckpt_elems));
+	HIPCHK(hipMalloc(&sa->d_best, sizeof(mgl_pk) * n));
+
+	const size_t K = sa->cfg.neighbours_per_step;
+	HIPCHK(hipMalloc(&sa->nbr.cost, sizeof(uint64_t) * K));
+	HIPCHK(hipMalloc(&sa->nbr.ndiffs, sizeof(uint32_t) * K));
+	HIPCHK(hipMalloc(&sa->nbr.walked, sizeof(uint32_t) * K));
+	HIPCHK(hipMalloc(&sa->nbr.dpos, sizeof(uint32_t) * K * MGL_MAX_DIFFS));
+	HIPCHK(hipMalloc(&sa->nbr.dold, sizeof(mgl_pk) * K * MGL_MAX_DIFFS));
+	HIPCHK(hipMalloc(&sa->nbr.dnew, sizeof(mgl_pk) * K * MGL_MAX_DIFFS));
+	HIPCHK(hipMalloc(&sa->d_aos, sizeof(mgl_packet) * n));
+	HIPCHK(hipMalloc(&sa->d_cum, sizeof(uint64_t) * n));
+	HIPCHK(hipMalloc(&sa->d_final_probs, sizeof(uint16_t) * ckpt_elems));
+	HIPCHK(hipMalloc(&sa->d_topk_pk, sizeof(mgl_pk) * 64));
+	HIPCHK(hipMalloc(&sa->d_topk_cost, sizeof(uint64_t) * 64));
+	HIPCHK(hipMalloc(&sa->d_small, sizeof(uint32_t) * 16));
+	sa->sub_cap = 1u << 20;
+	HIPCHK(hipMalloc(&sa->d_sub_offs, sizeof(uint32_t) * sa->sub_cap));
+	HIPCHK(hipMalloc(&sa->d_sub_lens, sizeof(uint32_t) * sa->sub_cap));
+
+	/* LDS budget: 4 KiB cost table + per wave {probabilities, 2x272 length prices, journal} */
+	sa->per_wave_bytes = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u);
+	sa->waves_per_block = 4;
+	while (sa->waves_per_block > 1 && 4096u + sa->waves_per_block * sa->per_wave_bytes > 160u * 1024u) sa->waves_per_block--;
+	sa->nbr_lds = 4096u + sa->waves_per_block * sa->per_wave_bytes;
+	sa->walk_lds = 4096u + ckpt_elems * 2u + 544u * 4u;
+	HIPCHK(hipFuncSetAttribute((const void*)k_neighbours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr_lds));
+	HIPCHK(hipFuncSetAttribute((const void*)k_rebuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->walk_lds));
+	HIPCHK(hipFuncSetAttribute((const void*)k_topk_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->walk_lds));
+
+	sa->sqrt_thresh = ceil_sqrt_u64(sa->cfg.iters_per_epoch);
+
+	/* packet_slab_new: all-literal current and best slabs */
+	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
+	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->d_best, sa->ctx.n);
+	HIPCHK(hipGetLastError());
+	int rc = launch_rebuild(sa, sa->base, 0, nullptr, nullptr);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	return MGL_OK;
+}
+
+extern "C" mgl_sa* mgl_sa_create(const uint8_t* data, size_t n, mgl_properties props, const mgl_sa_config* cfg)
+{
+	if (!data || n == 0 || n > 0xFFFFFF00ull || !cfg) { fail(MGL_EINVAL, "mgl_sa_create: bad data/size/config"); return nullptr; }
+	if (props.lc + props.lp > 4 || props.pb > 4 || props.lc > 8) { fail(MGL_EINVAL, "mgl_sa_create: unsupported lc/lp/pb"); return nullptr; }
+	mgl_sa* sa = new (std::nothrow) mgl_sa();
+	if (!sa) { fail(MGL_ENOMEM, "mgl_sa_create: out of host memory"); return nullptr; }
+	sa->cfg = *cfg;
+	sa->props = props;
+	sa->n = (uint32_t)n;
+	sa->device = cfg->device;
+	if (sa->cfg.neighbours_per_step == 0) sa->cfg.neighbours_per_step = 1;
+	if (sa->cfg.neighbours_per_step > (1u << 20)) { delete sa; fail(MGL_EINVAL, "neighbours_per_step > 2^20"); return nullptr; }
+	if (sa->cfg.top_k == 0) sa->cfg.top_k = 20;
+	if (sa->cfg.top_k > MGL_MAX_TOPK) { delete sa; fail(MGL_EINVAL, "top_k > 32"); return nullptr; }
+	if (sa->cfg.dict_limit == 0) sa->cfg.dict_limit = 0x400000u;
+	if (sa->cfg.iters_per_epoch == 0) sa->cfg.iters_per_epoch = n;
+	int rc = create_impl(sa, data, n);
+	if (rc != MGL_OK) {
+		std::string keep = g_err;
+		mgl_sa_destroy(sa);
+		g_err = keep;
+		return nullptr;
+	}
+	return sa;
+}
+
+static int read_ctl(mgl_sa* sa, BaseMem& b, Control* out)
+{
+	HIPCHK(hipMemcpyAsync(out, b.ctl, sizeof(Control), hipMemcpyDeviceToHost, sa->stream));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	return MGL_OK;
+}
+static int write_ctl(mgl_sa* sa, BaseMem& b, const Control* in)
+{
+	HIPCHK(hipMemcpyAsync(b.ctl, in, sizeof(Control), hipMemcpyHostToDevice, sa->stream));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	return MGL_OK;
+}
+
+extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	HIPCHK(hipSetDevice(sa->device));
+	if (from_best) HIPCHK(hipMemcpyAsync(sa->base.v.slab, sa->d_best, sizeof(mgl_pk) * (size_t)sa->n, hipMemcpyDeviceToDevice, sa->stream));
+	else {
+		hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
+		HIPCHK(hipGetLastError());
+	}
+	Control c;
+	int rc = read_ctl(sa, sa->base, &c);
+	if (rc) return rc;
+	c.iter = 0; c.cur_cost = 0; c.phase = phase; c.accepted_flag = 0; c.copy_best_flag = 0;
+	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
+	if ((rc = launch_rebuild(sa, sa->base, 0, nullptr, nullptr))) return rc;
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	return MGL_OK;
+}
+
+extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
+{
+	if (!sa || !packets) return fail(MGL_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(sa->device));
+	int rc = import_slab(sa, packets, sa->base.v.slab);
+	if (rc) return rc;
+	Control c;
+	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
+	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
+	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
+	if ((rc = launch_rebuild(sa, sa->base, 0, nullptr, nullptr))) return rc;
+	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
+	if (c.error_flags) return fail(MGL_EINVAL, "mgl_sa_set_slab: slab is not a valid parse");
+	return MGL_OK;
+}
+
+static hipEvent_t pool_event(mgl_sa* sa, size_t i)
+{
+	while (sa->ev_pool.size() <= i) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreate(&e) != hipSuccess) return nullptr;
+		sa->ev_pool.push_back(e);
+	}
+	return sa->ev_pool[i];
+}
+
+extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	HIPCHK(hipSetDevice(sa->device));
+	Control before, after;
+	int rc = read_ctl(sa, sa->base, &before);
+	if (rc) return rc;
+	const bool timing = (sa->cfg.flags & MGL_F_TIMING) != 0;
+	const uint64_t timed_steps = timing ? (steps < 512 ? steps : 512) : 0;
+	const uint32_t K = sa->cfg.neighbours_per_step;
+	HIPCHK(hipEventRecord(sa->ev_begin, sa->stream));
+	for (uint64_t s = 0; s < steps; s++) {
+		const bool t = s < timed_steps;
+		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
+		if ((rc = launch_neighbours(sa, ~0ull))) return rc;
+		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
+		hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
+		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh);
+		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
+		                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+		HIPCHK(hipGetLastError());
+		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
+		if ((rc = launch_rebuild(sa, sa->base, 1, nullptr, nullptr))) return rc;
+		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
+	}
+	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	if ((rc = read_ctl(sa, sa->base, &after))) return rc;
+	if (stats) {
+		memset(stats, 0, sizeof *stats);
+		stats->steps = after.gstep - before.gstep;
+		stats->evaluations = after.evals - before.evals;
+		stats->failed = after.failed - before.failed;
+		stats->accepted = after.accepted - before.accepted;
+		stats->improved = after.improved - before.improved;
+		stats->packets_evaluated = after.packets_eval - before.packets_eval;
+		stats->current_cost = after.cur_cost;
+		stats->best_cost = after.best_cost;
+		stats->packets = after.packets;
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, sa->ev_begin, sa->ev_end));
+		stats->gpu_ms_total = ms;
+		for (uint64_t s = 0; s < timed_steps; s++) {
+			HIPCHK(hipEventElapsedTime(&ms, sa->ev_pool[4 * s + 0], sa->ev_pool[4 * s + 1]));
+			stats->gpu_ms_neighbours += ms;
+			HIPCHK(hipEventElapsedTime(&ms, sa->ev_pool[4 * s + 2], sa->ev_pool[4 * s + 3]));
+			stats->gpu_ms_rebuild += ms;
+		}
+		stats->neighbour_launches = timed_steps;
+	}
+	if (after.error_flags) {
+		char buf[96];
+		snprintf(buf, sizeof buf, "mgl_sa_run: device consistency check failed (flags 0x%x)", after.error_flags);
+		return fail(MGL_EDEVICE, buf);
+	}
+	return MGL_OK;
+}
+
+extern "C" int mgl_sa_current(mgl_sa* sa, mgl_packet* packets_out, uint64_t* perplexity_out)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = read_ctl(sa, sa->base, &c);
+	if (rc) return rc;
+	if (perplexity_out) *perplexity_out = c.rebuild_cost;
+	if (packets_out) return export_slab(sa, sa->base.v.slab, packets_out);
+	return MGL_OK;
+}
+extern "C" int mgl_sa_best(mgl_sa* sa, mgl_packet* packets_out, uint64_t* perplexity_out)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = read_ctl(sa, sa->base, &c);
+	if (rc) return rc;
+	if (perplexity_out) *perplexity_out = c.best_cost;
+	if (packets_out) return export_slab(sa, sa->d_best, packets_out);
+	return MGL_OK;
+}
+
+/* run the walk kernel over `packets` in the scratch base */
+static int scratch_walk(mgl_sa* sa, const mgl_packet* packets, bool want_cum, bool want_probs, Control* out)
+{
+	int rc = import_slab(sa, packets, sa->scratch.v.slab);
+	if (rc) return rc;
+	HIPCHK(hipMemsetAsync(sa->scratch.ctl, 0, sizeof(Control), sa->stream));
+	if ((rc = launch_rebuild(sa, sa->scratch, 0, want_cum ? sa->d_cum : nullptr, want_probs ? sa->d_final_probs : nullptr))) return rc;
+	if ((rc = read_ctl(sa, sa->scratch, out))) return rc;
+	if (out->error_flags) return fail(MGL_EINVAL, "slab is not a valid parse of the input");
+	return MGL_OK;
+}
+
+extern "C" int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t perplexity)
+{
+	if (!sa || !packets) return fail(MGL_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = scratch_walk(sa, packets, false, false, &c);
+	if (rc) return rc;
+	if (c.rebuild_cost != perplexity) return fail(MGL_EINVAL, "mgl_sa_set_best: perplexity does not match the slab");
+	HIPCHK(hipMemcpyAsync(sa->d_best, sa->scratch.v.slab, sizeof(mgl_pk) * (size_t)sa->n, hipMemcpyDeviceToDevice, sa->stream));
+	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
+	c.best_cost = perplexity;
+	return write_ctl(sa, sa->base, &c);
+}
+
+extern "C" int mgl_cost_slab(mgl_sa* sa, const mgl_packet* packets, uint64_t* total, uint64_t* per_packet_cumulative,
+                             size_t* npackets)
+{
+	if (!sa || !packets) return fail(MGL_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = scratch_walk(sa, packets, per_packet_cumulative != nullptr, false, &c);
+	if (rc) return rc;
+	if (total) *total = c.rebuild_cost;
+	if (npackets) *npackets = (size_t)c.packets;
+	if (per_packet_cumulative)
+		HIPCHK(hipMemcpy(per_packet_cumulative, sa->d_cum, sizeof(uint64_t) * (size_t)c.packets, hipMemcpyDeviceToHost));
+	return MGL_OK;
+}
+
+extern "C" int mgl_final_state(mgl_sa* sa, const mgl_packet* packets, uint16_t* probs_out, size_t probs_cap,
+                               uint8_t* ctx_state_out, uint32_t dists_out[4])
+{
+	if (!sa || !packets) return fail(MGL_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = scratch_walk(sa, packets, false, true, &c);
+	if (rc) return rc;
+	if (ctx_state_out) *ctx_state_out = (uint8_t)c.final_ctx_state;
+	if (dists_out) memcpy(dists_out, c.final_dists, sizeof c.final_dists);
+	if (probs_out) {
+		const uint32_t total = sa->ctx.L.total, lit = total - MGL_OFF_LIT;
+		if (probs_cap < total) return fail(MGL_ERANGE, "probs_out too small");
+		std::vector<uint16_t> mine(total);
+		HIPCHK(hipMemcpy(mine.data(), sa->d_final_probs, sizeof(uint16_t) * total, hipMemcpyDeviceToHost));
+		/* reference struct order (lzma_state.h:47-53): lit | len | rep_len | dist | ctx_state */
+		uint16_t* o = probs_out;
+		memcpy(o, &mine[MGL_OFF_LIT], 2 * lit); o += lit;
+		memcpy(o, &mine[MGL_OFF_LEN], 2 * 514); o += 514;
+		memcpy(o, &mine[MGL_OFF_REP_LEN], 2 * 514); o += 514;
+		memcpy(o, &mine[MGL_OFF_DIST], 2 * 387); o += 387;
+		memcpy(o, &mine[0], 2 * 432);
+	}
+	return MGL_OK;
+}
+
+extern "C" int mgl_top_k(mgl_sa* sa, const mgl_packet* packets, size_t position, mgl_packet* out, uint64_t* costs, size_t* count)
+{
+	if (!sa || !packets || !out || !costs || !count) return fail(MGL_EINVAL, "null argument");
+	if (position >= sa->n) return fail(MGL_ERANGE, "position outside the input");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = scratch_walk(sa, packets, false, false, &c);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_topk_probe, dim3(1), dim3(64), sa->walk_lds, sa->stream, sa->ctx, sa->scratch.v, (uint32_t)position,
+	                   sa->d_topk_pk, sa->d_topk_cost, sa->d_small);
+	HIPCHK(hipGetLastError());
+	uint32_t cnt = 0;
+	mgl_pk pk[64];
+	uint64_t cs[64];
+	HIPCHK(hipMemcpyAsync(&cnt, sa->d_small, sizeof cnt, hipMemcpyDeviceToHost, sa->stream));
+	HIPCHK(hipMemcpyAsync(pk, sa->d_topk_pk, sizeof pk, hipMemcpyDeviceToHost, sa->stream));
+	HIPCHK(hipMemcpyAsync(cs, sa->d_topk_cost, sizeof cs, hipMemcpyDeviceToHost, sa->stream));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	if (cnt == ~0u) return fail(MGL_ERANGE, "position is not on the slab's walk");
+	for (uint32_t i = 0; i < cnt; i++) {
+		out[i].type = (uint8_t)mgl_pk_type(pk[i]); out[i].dist = mgl_pk_dist(pk[i]); out[i].len = (uint16_t)mgl_pk_len(pk[i]);
+		costs[i] = cs[i];
+	}
+	*count = cnt;
+	return MGL_OK;
+}
+
+extern "C" int mgl_substrings(mgl_sa* sa, size_t pos, size_t max_len, uint32_t* offsets, uint32_t* lengths, size_t cap, size_t* count)
+{
+	if (!sa || !count) return fail(MGL_EINVAL, "null argument");
+	if (pos >= sa->n) return fail(MGL_ERANGE, "position outside the input");
+	HIPCHK(hipSetDevice(sa->device));
+	const uint32_t dcap = cap < sa->sub_cap ? (uint32_t)cap : sa->sub_cap;
+	DevCtx c = sa->ctx;
+	c.dict_limit = 0xFFFFFFFFu; /* the index query itself has no window (substring_enumerator.c:97 is a todo) */
+	hipLaunchKernelGGL(k_substrings, dim3(1), dim3(1), 0, sa->stream, c, (uint32_t)pos, (uint32_t)max_len, sa->d_sub_offs,
+	                   sa->d_sub_lens, dcap, sa->d_small);
+	HIPCHK(hipGetLastError());
+	uint32_t cnt = 0;
+	HIPCHK(hipMemcpyAsync(&cnt, sa->d_small, sizeof cnt, hipMemcpyDeviceToHost, sa->stream));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	const uint32_t take = cnt < dcap ? cnt : dcap;
+	if (offsets && take) HIPCHK(hipMemcpy(offsets, sa->d_sub_offs, sizeof(uint32_t) * take, hipMemcpyDeviceToHost));
+	if (lengths && take) HIPCHK(hipMemcpy(lengths, sa->d_sub_lens, sizeof(uint32_t) * take, hipMemcpyDeviceToHost));
+	*count = cnt;
+	return MGL_OK;
+}
+
+extern "C" int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* diffs, uint32_t* ndiffs, size_t diff_cap)
+{
+	if (!sa || !costs) return fail(MGL_EINVAL, "null argument");
+	HIPCHK(hipSetDevice(sa->device));
+	int rc = launch_neighbours(sa, global_step);
+	if (rc) return rc;
+	const size_t K = sa->cfg.neighbours_per_step;
+	HIPCHK(hipMemcpyAsync(costs, sa->nbr.cost, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, sa->stream));
+	std::vector<uint32_t> nd(K), dpos;
+	std::vector<mgl_pk> dold, dnew;
+	HIPCHK(hipMemcpyAsync(nd.data(), sa->nbr.ndiffs, sizeof(uint32_t) * K, hipMemcpyDeviceToHost, sa->stream));
+	if (diffs) {
+		dpos.resize(K * MGL_MAX_DIFFS); dold.resize(K * MGL_MAX_DIFFS); dnew.resize(K * MGL_MAX_DIFFS);
+		HIPCHK(hipMemcpyAsync(dpos.data(), sa->nbr.dpos, sizeof(uint32_t) * dpos.size(), hipMemcpyDeviceToHost, sa->stream));
+		HIPCHK(hipMemcpyAsync(dold.data(), sa->nbr.dold, sizeof(mgl_pk) * dold.size(), hipMemcpyDeviceToHost, sa->stream));
+		HIPCHK(hipMemcpyAsync(dnew.data(), sa->nbr.dnew, sizeof(mgl_pk) * dnew.size(), hipMemcpyDeviceToHost, sa->stream));
+	}
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	for (size_t j = 0; j < K; j++) {
+		if (ndiffs) ndiffs[j] = nd[j];
+		if (!diffs) continue;
+		for (size_t e = 0; e < nd[j] && e < diff_cap; e++) {
+			mgl_diff* d = &diffs[j * diff_cap + e];
+			const mgl_pk o = dold[j * MGL_MAX_DIFFS + e], w = dnew[j * MGL_MAX_DIFFS + e];
+			d->position = dpos[j * MGL_MAX_DIFFS + e];
+			d->old_packet.type = (uint8_t)mgl_pk_type(o); d->old_packet.dist = mgl_pk_dist(o); d->old_packet.len = (uint16_t)mgl_pk_len(o);
+			d->new_packet.type = (uint8_t)mgl_pk_type(w); d->new_packet.dist = mgl_pk_dist(w); d->new_packet.len = (uint16_t)mgl_pk_len(w);
+		}
+	}
+	return MGL_OK;
+}

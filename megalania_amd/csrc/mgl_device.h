@@ -1,0 +1,174 @@
+/*
+ * mgl_device.h -- device-side building blocks shared by the kernels in mgl_kernels.hip.
+ * gfx950 only: 64-lane wavefronts, probabilities and the bit-cost table in LDS.
+ *
+ * Conventions
+ *   - one wavefront works on one slab walk.  Control flow is wave-uniform; walk state
+ *     (position, ctx_state, rep distances) is kept in scalar registers via readfirstlane.
+ *   - lane e of the wave evaluates event slot e of the current packet (mgl_model.h), so a
+ *     packet costs one LDS read-modify-write round trip; per-lane u64 partial sums are
+ *     reduced once at the end (u64 addition commutes, so the total is bit-exact).
+ *   - the walk reads the slab and the input through a 64-position register window
+ *     (one coalesced load per 64 bytes of input) and fetches entries with v_readlane.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mgl_model.h"
+
+#define MGL_WAVE 64
+#define MGL_CKPT_SHIFT 10u          /* one prefix checkpoint per 1024 input bytes */
+#define MGL_MAX_DIFFS 64u           /* journal capacity per neighbour */
+#define MGL_MAX_TOPK 32u
+#define MGL_SEQ_MASK ((1ull << 44) - 1ull)
+#define MGL_INVALID_COST (~0ull)
+
+struct DevCtx {
+	const uint8_t* data;        /* n bytes (+64 bytes of zero padding) */
+	uint32_t n;
+	const uint32_t* bucket_off; /* 65537 */
+	const uint32_t* bucket_pos; /* n-1 positions, ascending inside each bigram bucket */
+	const uint16_t* cost_tbl;   /* 2048 x u16 */
+	mgl_layout L;
+	uint32_t dict_limit;
+	uint32_t max_scan;
+	uint32_t top_k;
+};
+
+struct CkptHdr {
+	uint32_t pos, ctx_state;
+	uint32_t dists[4];
+	uint32_t ordinal, pad;
+	uint64_t cum;
+};
+
+struct BaseView {
+	mgl_pk* slab;          /* n packed entries, position-indexed */
+	uint64_t* onwalk;      /* bitmap: bit (p&63) of word p>>6 set iff a packet starts at p */
+	uint16_t* ckpt_probs;  /* nckpt x ckpt_elems */
+	CkptHdr* ckpt_hdr;
+	uint32_t nckpt;
+	uint32_t ckpt_elems;   /* probabilities per checkpoint, rounded up to a multiple of 8 */
+};
+
+struct Control {
+	uint64_t cur_cost, best_cost;
+	uint64_t gstep, iter;
+	uint64_t evals, failed, accepted, improved, packets_eval;
+	uint64_t packets, rebuild_cost;
+	uint32_t phase;
+	uint32_t accepted_flag, copy_best_flag, dirty_pos, winner;
+	uint32_t final_ctx_state;
+	uint32_t final_dists[4];
+	uint32_t error_flags;
+};
+#define MGL_ERR_REBUILD_MISMATCH 1u
+#define MGL_ERR_WALK_OVERRUN 2u
+
+struct NbrOut {
+	uint64_t* cost;    /* K */
+	uint32_t* ndiffs;  /* K */
+	uint32_t* walked;  /* K: packets costed by the neighbour (from its checkpoint on) */
+	uint32_t* dpos;    /* K x MGL_MAX_DIFFS */
+	mgl_pk* dold;
+	mgl_pk* dnew;
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t x, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t x, uint32_t l)
+{
+	return (uint64_t)rdlane((uint32_t)x, l) | ((uint64_t)rdlane((uint32_t)(x >> 32), l) << 32);
+}
+__device__ __forceinline__ uint64_t uni64(uint64_t x)
+{
+	return (uint64_t)uni((uint32_t)x) | ((uint64_t)uni((uint32_t)(x >> 32)) << 32);
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t x, int src)
+{
+	uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src, 64);
+	uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), src, 64);
+	return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t x, int delta)
+{
+	uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, delta, 64);
+	uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), delta, 64);
+	return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
+{
+	for (int o = 32; o > 0; o >>= 1) {
+		uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+		uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+		v += (uint64_t)lo | ((uint64_t)hi << 32);
+	}
+	return v;
+}
+/* LDS written by some lanes of this wave is read by others: keep the compiler from moving
+ * accesses across (the hardware executes a wave's LDS operations in order). */
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+/* ------------------------------------------------------------------ the slab walk */
+struct Walk {
+	mgl_wstate st;   /* uniform */
+	uint64_t acc;    /* per-lane partial perplexity */
+	uint32_t wbase;  /* window: positions [wbase, wbase+64) */
+	mgl_pk wpk;
+	uint32_t wbyte;
+	uint32_t packets;
+};
+
+__device__ __forceinline__ void walk_reset(Walk& w)
+{
+	w.st.pos = 0; w.st.ctx_state = 0;
+	w.st.dists[0] = w.st.dists[1] = w.st.dists[2] = w.st.dists[3] = 0;
+	w.acc = 0; w.wbase = 0xFFFFFFFFu; w.wpk = 0; w.wbyte = 0; w.packets = 0;
+}
+
+/* make the window cover st.pos */
+__device__ __forceinline__ void walk_window(Walk& w, const DevCtx& c, const mgl_pk* slab, uint32_t lane)
+{
+	uint32_t base = w.st.pos & ~63u;
+	if (base != w.wbase) {
+		uint32_t p = base + lane;
+		w.wpk = p < c.n ? slab[p] : 0;
+		w.wbyte = c.data[p < c.n ? p : c.n]; /* data has >= 64 bytes of zero padding */
+		w.wbase = base;
+	}
+}
+__device__ __forceinline__ mgl_pk walk_slab_at(const Walk& w, uint32_t pos) { return rdlane64(w.wpk, pos - w.wbase); }
+__device__ __forceinline__ uint32_t walk_byte_at(const Walk& w, uint32_t pos) { return rdlane(w.wbyte, pos - w.wbase); }
+
+/* Cost one packet at the walk's position against the adaptive model in LDS and advance.
+ * UPDATE=false leaves probabilities untouched (candidate costing) and does not advance. */
+template <bool UPDATE>
+__device__ __forceinline__ void walk_packet(Walk& w, const DevCtx& c, uint16_t* probs, const uint16_t* T,
+                                            uint32_t type, uint32_t dist, uint32_t len, uint32_t lane)
+{
+	uint32_t pos = w.st.pos;
+	uint32_t byte = walk_byte_at(w, pos);
+	uint32_t match_byte = 0, prev_byte = 0;
+	if (type == MGL_LITERAL) {
+		if (w.st.ctx_state >= 7 && w.st.dists[0] < pos) match_byte = c.data[pos - w.st.dists[0] - 1];
+		if (c.L.lc > 0 && pos > 0) prev_byte = c.data[pos - 1];
+	}
+	mgl_plan pl;
+	mgl_plan_packet(&c.L, &w.st, type, dist, len, byte, match_byte, prev_byte, &pl);
+	if (lane < pl.nev) {
+		uint32_t ctx, bit;
+		mgl_plan_event(&pl, lane, &ctx, &bit);
+		uint32_t p = probs[ctx];
+		w.acc += T[bit ? 2048u - p : p];
+		if (UPDATE) probs[ctx] = (uint16_t)mgl_prob_update(p, bit);
+	}
+	if (lane == 0) w.acc += (uint64_t)pl.ndirect << 11;
+	if (UPDATE) {
+		mgl_advance(&w.st, type, dist, len);
+		w.packets++;
+	}
+}

@@ -1,0 +1,727 @@
+/*
+ * mgl_kernels.hip -- CDNA4 (gfx950) kernels of the SA hot path.
+ *
+ *   k_rebuild      walk the base slab: on-walk bitmap, prefix checkpoints, total cost
+ *                  (== the loop of main.c:116-118 under perplexity_encoder.c:6-17)
+ *   k_neighbours   one wavefront per candidate neighbour: target pick, prefix from the
+ *                  nearest checkpoint, mutate (packet_slab_neighbour.c:119-152), wave-wide
+ *                  top-K (top_k_packet_finder.c:95-125 over packet_enumerator.c:57-74 and
+ *                  substring_enumerator.c:85-105), repair + cost to the end (:82-117)
+ *   k_decide       best-of-K reduction + the accept rule of main.c:86-96, winner's journal
+ *                  applied to the base slab
+ *   k_copy_best    main.c:91
+ *   k_topk_probe / k_substrings / k_import / k_export   parity hooks and layout conversion
+ *
+ * Integer table-lookup work: no MFMA.  Probabilities (u16) and the bit-cost table live in
+ * LDS; the input, the slab and the match index stay in HBM/L2 and are read coalesced.
+ */
+#include "mgl_device.h"
+
+/* ================================================================== top-K (wave-wide) */
+
+struct TopK {
+	uint64_t key;   /* lane i (< count) holds the i-th best key; others ~0 */
+	uint32_t count; /* uniform */
+	uint32_t k;
+};
+
+__device__ __forceinline__ uint64_t topk_make_key(uint32_t cost, uint64_t seq)
+{
+	return ((uint64_t)cost << 44) | (MGL_SEQ_MASK - seq);
+}
+__device__ __forceinline__ uint64_t topk_threshold(const TopK& t)
+{
+	return t.count < t.k ? MGL_INVALID_COST : shfl64(t.key, (int)t.k - 1);
+}
+/* every lane may offer one candidate key (or ~0); all offers better than the current
+ * K-th best are merged into the sorted list */
+__device__ __forceinline__ void topk_offer(TopK& t, uint64_t cand, uint32_t lane)
+{
+	for (;;) {
+		uint64_t thr = topk_threshold(t);
+		unsigned long long m = __ballot(cand < thr);
+		if (!m) break;
+		int src = __ffsll((long long)m) - 1;
+		uint64_t x = shfl64(cand, src);
+		uint32_t r = (uint32_t)__popcll(__ballot(t.key < x));
+		uint64_t up = shfl_up64(t.key, 1);
+		if (lane == r) t.key = x;
+		else if (lane > r) t.key = up;
+		if (lane >= t.k) t.key = MGL_INVALID_COST;
+		if (t.count < t.k) t.count++;
+		if ((int)lane == src) cand = MGL_INVALID_COST;
+	}
+}
+
+__device__ __forceinline__ uint32_t bit_cost(const uint16_t* probs, const uint16_t* T, uint32_t ctx, uint32_t bit)
+{
+	uint32_t p = probs[ctx];
+	return T[bit ? 2048u - p : p];
+}
+__device__ __forceinline__ uint32_t tree_cost(const uint16_t* probs, const uint16_t* T, uint32_t base,
+                                              uint32_t val, uint32_t nbits)
+{
+	uint32_t m = 1, c = 0;
+	for (uint32_t i = nbits; i-- > 0;) {
+		uint32_t b = (val >> i) & 1u;
+		c += bit_cost(probs, T, base + m, b);
+		m = (m << 1) | b;
+	}
+	return c;
+}
+__device__ __forceinline__ uint32_t rev_tree_cost(const uint16_t* probs, const uint16_t* T, uint32_t base,
+                                                  uint32_t val, uint32_t nbits)
+{
+	uint32_t m = 1, c = 0;
+	for (uint32_t i = 0; i < nbits; i++) {
+		uint32_t b = val & 1u;
+		val >>= 1;
+		c += bit_cost(probs, T, base + m, b);
+		m = (m << 1) | b;
+	}
+	return c;
+}
+/* lzma_packet_encoder.c:42-63 as a read-only cost */
+__device__ __forceinline__ uint32_t length_cost(const uint16_t* probs, const uint16_t* T, uint32_t base,
+                                                uint32_t len, uint32_t pos_state)
+{
+	uint32_t l = len - 2;
+	if (l < 8) return bit_cost(probs, T, base, 0) + tree_cost(probs, T, base + MGL_LEN_LOW + pos_state * 8, l, 3);
+	uint32_t c = bit_cost(probs, T, base, 1);
+	if (l < 16) return c + bit_cost(probs, T, base + 1, 0) + tree_cost(probs, T, base + MGL_LEN_MID + pos_state * 8, l - 8, 3);
+	return c + bit_cost(probs, T, base + 1, 1) + tree_cost(probs, T, base + MGL_LEN_HIGH, l - 16, 8);
+}
+
+/* first index in [a, b) whose bucket position is >= x: 64-ary search, one probe per lane */
+__device__ __forceinline__ uint32_t bucket_lower_bound(const uint32_t* bp, uint32_t a, uint32_t b, uint32_t x, uint32_t lane)
+{
+	while (b > a) {
+		uint32_t span = b - a;
+		uint32_t step = (span + 63u) / 64u;
+		uint32_t idx = a + lane * step;
+		bool ge = idx >= b ? true : (bp[idx] >= x);
+		unsigned long long m = __ballot(ge);
+		/* the predicate is monotone in the lane; f = first lane that holds (64 if none).
+		 * lane 0 probes a itself; the answer lies in (probe[f-1], probe[f]] */
+		int f = m ? __ffsll((long long)m) - 1 : 64;
+		if (f == 0) break; /* answer is a */
+		uint32_t na = a + (uint32_t)(f - 1) * step + 1u;
+		uint32_t nb = a + (uint32_t)f * step;
+		if (nb > b) nb = b;
+		a = na; b = nb;
+	}
+	return a;
+}
+
+/* top_k_packet_finder_find (top_k_packet_finder.c:120-125): enumerate every legal next
+ * packet at the walk's state, cost each from the adapted model (cost = perplexity/length,
+ * :115-116), keep the k best.  Order-independent ("canonical") selection: better = lower
+ * cost, then later in the reference's enumeration order (the reference's `<=`, :89).
+ * lencost: LDS scratch, 2 x 272 u32. */
+__device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_t* probs, const uint16_t* T,
+                          uint32_t* lencost, mgl_pk incumbent, uint32_t lane)
+{
+	const uint32_t pos = w.st.pos;
+	const uint32_t state = w.st.ctx_state;
+	const uint32_t pos_state = pos & ((1u << c.L.pb) - 1u);
+	const uint32_t sp = (state << 4) + pos_state;
+	t.key = MGL_INVALID_COST;
+	t.count = 0;
+	t.k = c.top_k;
+
+	/* packet headers, lzma_packet_encoder.c:13-40 */
+	const uint32_t c_m1 = bit_cost(probs, T, MGL_CS_IS_MATCH + sp, 1);
+	const uint32_t c_r0 = bit_cost(probs, T, MGL_CS_IS_REP + state, 0);
+	const uint32_t c_r1 = bit_cost(probs, T, MGL_CS_IS_REP + state, 1);
+	const uint32_t g0_0 = bit_cost(probs, T, MGL_CS_G0 + state, 0), g0_1 = bit_cost(probs, T, MGL_CS_G0 + state, 1);
+	const uint32_t g1_0 = bit_cost(probs, T, MGL_CS_G1 + state, 0), g1_1 = bit_cost(probs, T, MGL_CS_G1 + state, 1);
+	const uint32_t g2_0 = bit_cost(probs, T, MGL_CS_G2 + state, 0), g2_1 = bit_cost(probs, T, MGL_CS_G2 + state, 1);
+	const uint32_t l_0 = bit_cost(probs, T, MGL_CS_REP0_LONG + sp, 0), l_1 = bit_cost(probs, T, MGL_CS_REP0_LONG + sp, 1);
+	const uint32_t hdr_match = c_m1 + c_r0;
+	const uint32_t hdr_rep = c_m1 + c_r1;
+	const uint32_t hdr_lr0 = hdr_rep + g0_0 + l_1, hdr_lr1 = hdr_rep + g0_1 + g1_0;
+	const uint32_t hdr_lr2 = hdr_rep + g0_1 + g1_1 + g2_0, hdr_lr3 = hdr_rep + g0_1 + g1_1 + g2_1;
+
+	/* length price tables for both length coders */
+	for (uint32_t l = 2 + lane; l <= MGL_MAX_MATCH; l += 64) {
+		lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
+		lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
+	}
+	wave_sync();
+
+	/* LITERAL and SHORT_REP, packet_enumerator.c:60-66 */
+	{
+		uint64_t cand = MGL_INVALID_COST;
+		uint32_t byte = walk_byte_at(w, pos);
+		uint32_t rep_byte = (pos > 0 && w.st.dists[0] < pos) ? c.data[pos - w.st.dists[0] - 1] : 0x100u;
+		uint32_t prev_byte = (c.L.lc > 0 && pos > 0) ? c.data[pos - 1] : 0;
+		mgl_plan pl;
+		mgl_plan_packet(&c.L, &w.st, MGL_LITERAL, 0, 1, byte, rep_byte, prev_byte, &pl);
+		uint32_t ec = 0;
+		if (lane < pl.nev) {
+			uint32_t ctx, bit;
+			mgl_plan_event(&pl, lane, &ctx, &bit);
+			ec = bit_cost(probs, T, ctx, bit);
+		}
+		uint32_t lit = (uint32_t)wave_sum64(ec);
+		if (lane == 0 && incumbent != MGL_PK_LITERAL) cand = topk_make_key(lit, 0);
+		if (lane == 1 && pos > 0 && byte == rep_byte && incumbent != MGL_PK_SHORT_REP)
+			cand = topk_make_key(hdr_rep + g0_0 + l_0, 1);
+		topk_offer(t, cand, lane);
+	}
+
+	/* substring_enumerator.c:85-105: nothing at the first and the last byte */
+	if (pos == 0 || pos >= c.n - 1) return;
+	const uint32_t bigram = ((uint32_t)walk_byte_at(w, pos) << 8) | c.data[pos + 1];
+	uint32_t lo = c.bucket_off[bigram], end = c.bucket_off[bigram + 1];
+	uint32_t hi = bucket_lower_bound(c.bucket_pos, lo, end, pos, lane); /* hits are < pos */
+	if (pos > c.dict_limit) lo = bucket_lower_bound(c.bucket_pos, lo, hi, pos - c.dict_limit, lane);
+	if (c.max_scan && hi - lo > c.max_scan) lo = hi - c.max_scan;
+	const uint32_t maxlen = (c.n - pos) < MGL_MAX_MATCH ? (c.n - pos) : MGL_MAX_MATCH;
+	const uint32_t inc_type = mgl_pk_type(incumbent), inc_len = mgl_pk_len(incumbent), inc_dist = mgl_pk_dist(incumbent);
+
+	for (uint32_t hb = lo; hb < hi; hb += 64) {
+		const uint32_t idx = hb + lane;
+		bool have = idx < hi;
+		uint32_t q = 0, d = 0, L = 0, repmask = 0;
+		uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, tail = 0;
+		if (have) {
+			q = c.bucket_pos[idx];
+			d = pos - q - 1;
+			/* match extension, substring_enumerator.c:99-103 */
+			L = 2;
+			while (L < maxlen && c.data[pos + L] == c.data[q + L]) L++;
+			repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
+			          (w.st.dists[3] == d ? 8u : 0u);
+			/* distance price per length context, lzma_packet_encoder.c:71-104 */
+			uint32_t slot = d, nlow = 0, low = 0, high = 0;
+			if (d >= 4) {
+				nlow = mgl_msb32(d) - 2; low = d & ((1u << nlow) - 1u); high = d >> nlow;
+				slot = nlow * 2 + high;
+				if (slot < 14) tail = rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_POS + (high << nlow) - slot, low, nlow);
+				else tail = ((nlow - 4) << 11) + rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_ALIGN, low & 15u, 4);
+			}
+			s0 = tree_cost(probs, T, MGL_OFF_DIST, slot, 6);
+			if (L > 2) s1 = tree_cost(probs, T, MGL_OFF_DIST + 64, slot, 6);
+			if (L > 3) s2 = tree_cost(probs, T, MGL_OFF_DIST + 128, slot, 6);
+			if (L > 4) s3 = tree_cost(probs, T, MGL_OFF_DIST + 192, slot, 6);
+		}
+		uint32_t len = 2, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
+		while (__ballot(have)) {
+			uint64_t thr = topk_threshold(t);
+			uint64_t cand = MGL_INVALID_COST;
+			while (have) {
+				uint32_t perp, ctype, cdist;
+				if (kind == 0) {
+					uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
+					perp = hdr_match + lencost[len - 2] + sc + tail;
+					ctype = MGL_MATCH; cdist = d;
+				} else {
+					uint32_t i = kind - 1;
+					uint32_t h = i == 0 ? hdr_lr0 : i == 1 ? hdr_lr1 : i == 2 ? hdr_lr2 : hdr_lr3;
+					perp = h + lencost[272 + len - 2];
+					ctype = MGL_LONG_REP; cdist = i;
+				}
+				uint64_t key = topk_make_key(perp / len, ((uint64_t)(q + 1) << 12) | ((uint64_t)len << 3) | kind);
+				bool skip = ctype == inc_type && len == inc_len && cdist == inc_dist; /* top_k_packet_finder.c:99-101 */
+				/* next candidate of this hit: packet_enumerator.c:48-54 order */
+				uint32_t nk = kind + 1;
+				while (nk <= 4 && !((repmask >> (nk - 1)) & 1u)) nk++;
+				if (nk <= 4) kind = nk; else { kind = 0; len++; if (len > L) have = false; }
+				if (!skip && key < thr) { cand = key; break; }
+			}
+			topk_offer(t, cand, lane);
+		}
+	}
+}
+
+/* decode a top-K key back into a packet */
+__device__ __forceinline__ mgl_pk topk_packet(uint64_t key, uint32_t pos)
+{
+	uint64_t seq = MGL_SEQ_MASK - (key & MGL_SEQ_MASK);
+	if (seq == 0) return MGL_PK_LITERAL;
+	if (seq == 1) return MGL_PK_SHORT_REP;
+	uint32_t q1 = (uint32_t)(seq >> 12), len = (uint32_t)(seq >> 3) & 0x1FFu, kind = (uint32_t)seq & 7u;
+	if (kind == 0) return mgl_pack(MGL_MATCH, pos - q1, len);
+	return mgl_pack(MGL_LONG_REP, kind - 1, len);
+}
+
+/* ================================================================== checkpoints */
+
+__device__ __forceinline__ void ckpt_store(const BaseView& b, const DevCtx& c, uint32_t ci, const uint16_t* probs,
+                                           const Walk& w, uint64_t cum, uint32_t lane)
+{
+	uint32_t* dst = (uint32_t*)(b.ckpt_probs + (size_t)ci * b.ckpt_elems);
+	const uint32_t* src = (const uint32_t*)probs;
+	for (uint32_t i = lane; i < b.ckpt_elems / 2; i += 64) dst[i] = src[i];
+	if (lane == 0) {
+		CkptHdr h;
+		h.pos = w.st.pos; h.ctx_state = w.st.ctx_state;
+		h.dists[0] = w.st.dists[0]; h.dists[1] = w.st.dists[1]; h.dists[2] = w.st.dists[2]; h.dists[3] = w.st.dists[3];
+		h.ordinal = w.packets; h.pad = 0; h.cum = cum;
+		b.ckpt_hdr[ci] = h;
+	}
+}
+__device__ __forceinline__ uint64_t ckpt_load(const BaseView& b, const DevCtx& c, uint32_t ci, uint16_t* probs,
+                                              Walk& w, uint32_t lane)
+{
+	const uint32_t* src = (const uint32_t*)(b.ckpt_probs + (size_t)ci * b.ckpt_elems);
+	uint32_t* dst = (uint32_t*)probs;
+	for (uint32_t i = lane; i < b.ckpt_elems / 2; i += 64) dst[i] = src[i];
+	const CkptHdr* h = &b.ckpt_hdr[ci];
+	walk_reset(w);
+	w.st.pos = uni(h->pos); w.st.ctx_state = uni(h->ctx_state);
+	w.st.dists[0] = uni(h->dists[0]); w.st.dists[1] = uni(h->dists[1]);
+	w.st.dists[2] = uni(h->dists[2]); w.st.dists[3] = uni(h->dists[3]);
+	w.packets = uni(h->ordinal);
+	uint64_t cum = uni64(h->cum);
+	wave_sync();
+	return cum;
+}
+
+/* ================================================================== k_rebuild */
+/* One wavefront walks the base slab from the checkpoint that precedes the first changed
+ * position (or from byte 0) to the end: rewrites the on-walk bitmap and the prefix
+ * checkpoints, counts packets and produces the slab's exact total cost.
+ * cum_out (nullable): running total after every packet (parity hook). */
+__global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* ctl, int from_dirty, uint64_t* cum_out,
+                                                uint16_t* final_probs)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	uint16_t* probs = (uint16_t*)(smem + 4096);
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t i = lane; i < 2048; i += 64) T[i] = c.cost_tbl[i];
+
+	Walk w;
+	uint64_t base_cum = 0;
+	uint32_t ci = 0;
+	if (from_dirty) {
+		if (!ctl->accepted_flag) return;
+		ci = uni(ctl->dirty_pos) >> MGL_CKPT_SHIFT;
+	}
+	if (ci == 0) {
+		for (uint32_t i = lane; i < b.ckpt_elems; i += 64) probs[i] = MGL_PROB_INIT;
+		walk_reset(w);
+		wave_sync();
+	} else {
+		base_cum = ckpt_load(b, c, ci, probs, w, lane);
+	}
+	uint32_t next_ck = ci; /* next checkpoint index to (re)write: covers positions >= next_ck << SHIFT */
+	/* on-walk bitmap: keep the bits below the restart position in its word */
+	uint32_t word = w.st.pos >> 6;
+	uint64_t bits = 0;
+	if (w.st.pos & 63u) bits = b.onwalk[word] & ((1ull << (w.st.pos & 63u)) - 1ull);
+
+	uint32_t guard = 0;
+	while (w.st.pos < c.n) {
+		const uint32_t pos = w.st.pos;
+		if (++guard > c.n) { if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); break; }
+		while (next_ck < b.nckpt && (next_ck << MGL_CKPT_SHIFT) <= pos) {
+			uint64_t cum = base_cum + wave_sum64(w.acc);
+			ckpt_store(b, c, next_ck, probs, w, cum, lane);
+			next_ck++;
+		}
+		/* flush finished bitmap words */
+		const uint32_t pw = pos >> 6;
+		if (pw != word) {
+			if (lane == 0) b.onwalk[word] = bits;
+			for (uint32_t z = word + 1 + lane; z < pw; z += 64) b.onwalk[z] = 0;
+			word = pw; bits = 0;
+		}
+		bits |= 1ull << (pos & 63u);
+		walk_window(w, c, b.slab, lane);
+		const mgl_pk pk = walk_slab_at(w, pos);
+		uint32_t type = mgl_pk_type(pk), len = mgl_pk_len(pk), dist = mgl_pk_dist(pk);
+		if (type < MGL_LITERAL || type > MGL_LONG_REP || len == 0 || pos + len > c.n) { /* corrupt entry: cost as literal */
+			type = MGL_LITERAL; len = 1; dist = 0;
+			if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
+		}
+		walk_packet<true>(w, c, probs, T, type, dist, len, lane);
+		if (cum_out) {
+			uint64_t cum = base_cum + wave_sum64(w.acc);
+			if (lane == 0) cum_out[w.packets - 1] = cum;
+		}
+	}
+	if (lane == 0) b.onwalk[word] = bits;
+	{
+		const uint32_t nwords = (c.n + 63u) >> 6;
+		for (uint32_t z = word + 1 + lane; z < nwords; z += 64) b.onwalk[z] = 0;
+	}
+	const uint64_t total = base_cum + wave_sum64(w.acc);
+	wave_sync();
+	if (final_probs) for (uint32_t i = lane; i < c.L.total; i += 64) final_probs[i] = probs[i];
+	if (lane == 0) {
+		ctl->packets = w.packets;
+		ctl->rebuild_cost = total;
+		ctl->final_ctx_state = w.st.ctx_state;
+		ctl->final_dists[0] = w.st.dists[0]; ctl->final_dists[1] = w.st.dists[1];
+		ctl->final_dists[2] = w.st.dists[2]; ctl->final_dists[3] = w.st.dists[3];
+		if (from_dirty) {
+			if (ctl->cur_cost != total) atomicOr(&ctl->error_flags, MGL_ERR_REBUILD_MISMATCH);
+			ctl->accepted_flag = 0;
+		}
+	}
+}
+
+/* ================================================================== k_neighbours */
+
+struct Journal {
+	uint32_t* pos; /* LDS, MGL_MAX_DIFFS */
+	mgl_pk* old;
+	mgl_pk* neu;
+	uint32_t count; /* uniform */
+	bool overflow;
+};
+__device__ __forceinline__ void journal_set(Journal& jn, uint32_t pos, mgl_pk old, mgl_pk neu, uint32_t lane)
+{
+	/* the mutated pair (first two entries) may be touched again by the repair */
+	for (uint32_t i = 0; i < jn.count && i < 2; i++) {
+		if (jn.pos[i] == pos) { if (lane == 0) jn.neu[i] = neu; wave_sync(); return; }
+	}
+	if (jn.count >= MGL_MAX_DIFFS) { jn.overflow = true; return; }
+	if (lane == 0) { jn.pos[jn.count] = pos; jn.old[jn.count] = old; jn.neu[jn.count] = neu; }
+	jn.count++;
+	wave_sync();
+}
+
+struct NbrRng { uint64_t key; uint32_t n; };
+__device__ __forceinline__ uint32_t nbr_draw(NbrRng& r) { return mgl_rng_draw(r.key, r.n++); }
+
+/* packet_slab_neighbour.c:56-72 with the canonical top-K order */
+__device__ bool pick_from_top_k(const DevCtx& c, const Walk& w, const uint16_t* probs, const uint16_t* T, uint32_t* lencost,
+                                mgl_pk incumbent, bool best, NbrRng& rng, uint32_t lane, mgl_pk* picked)
+{
+	TopK t;
+	topk_find(t, c, w, probs, T, lencost, incumbent, lane);
+	const uint32_t count = t.count;
+	if (count == 0) return false;
+	uint32_t choice = nbr_draw(rng) % count; /* :48-54 max of 8 draws */
+	for (int i = 0; i < 7; i++) { uint32_t x = nbr_draw(rng) % count; choice = x > choice ? x : choice; }
+	if (nbr_draw(rng) % 8u == 0 || best) choice = count - 1;
+	/* pop order is worst first: the (choice+1)-th pop is rank count-1-choice from the best */
+	uint64_t key = shfl64(t.key, (int)(count - 1 - choice));
+	*picked = topk_packet(key, w.st.pos);
+	return true;
+}
+
+/* packet_slab_neighbour.c:74-80: memcmp over the rep source, all lanes compare */
+__device__ __forceinline__ bool long_rep_ok(const DevCtx& c, const Walk& w, uint32_t idx, uint32_t len, uint32_t lane)
+{
+	const uint32_t rd = mgl_dist_at(&w.st, idx);
+	if (rd >= w.st.pos || w.st.pos + len > c.n) return false;
+	const uint32_t src = w.st.pos - rd - 1u;
+	bool bad = false;
+	for (uint32_t i = lane; i < len; i += 64) bad |= c.data[src + i] != c.data[w.st.pos + i];
+	return __ballot(bad) == 0;
+}
+
+/* One wavefront = one neighbour of the base slab (packet_slab_neighbour.c:154-173). */
+__global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const Control* ctl, uint64_t seed,
+                                                    uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	const uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	if (j >= K) return;
+	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
+	uint16_t* probs = (uint16_t*)mine;
+	uint32_t* lencost = (uint32_t*)(mine + (size_t)b.ckpt_elems * 2);
+	Journal jn;
+	jn.old = (mgl_pk*)(lencost + 544);
+	jn.neu = jn.old + MGL_MAX_DIFFS;
+	jn.pos = (uint32_t*)(jn.neu + MGL_MAX_DIFFS);
+	jn.count = 0; jn.overflow = false;
+
+	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
+	NbrRng rng; rng.key = mgl_rng_key(seed, gstep, j); rng.n = 0;
+
+	/* target: uniform over the packets of the walk by rejection sampling on positions
+	 * (the reference draws a packet ordinal, packet_slab_neighbour.c:162-163) */
+	uint32_t target;
+	{
+		uint32_t mydraw = lane < 32 ? mgl_rng_draw(rng.key, lane) % c.n : 0;
+		bool on = lane < 32 && ((b.onwalk[mydraw >> 6] >> (mydraw & 63u)) & 1ull);
+		unsigned long long m = __ballot(on);
+		if (m) {
+			int f = __ffsll((long long)m) - 1;
+			target = rdlane(mydraw, (uint32_t)f);
+			rng.n = (uint32_t)f + 1;
+		} else {
+			rng.n = 32;
+			uint32_t p = rdlane(mydraw, 31);
+			/* next on-walk position at or after p, else 0 */
+			const uint32_t nwords = (c.n + 63u) >> 6;
+			uint32_t wd = p >> 6;
+			uint64_t bits = b.onwalk[wd] & (~0ull << (p & 63u));
+			while (!bits && ++wd < nwords) bits = b.onwalk[wd];
+			target = bits ? (wd << 6) + (uint32_t)__ffsll((long long)bits) - 1u : 0u;
+			target = uni(target);
+		}
+	}
+
+	/* prefix: nearest checkpoint, then the unchanged packets up to the target (:165) */
+	Walk w;
+	const uint64_t base_cum = ckpt_load(b, c, target >> MGL_CKPT_SHIFT, probs, w, lane);
+	const uint32_t first_packet = w.packets;
+	while (w.st.pos < target) {
+		walk_window(w, c, b.slab, lane);
+		const mgl_pk pk = walk_slab_at(w, w.st.pos);
+		walk_packet<true>(w, c, probs, T, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), lane);
+	}
+	if (w.st.pos != target) { /* cannot happen for an on-walk target; fail safe */
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+		return;
+	}
+
+	/* mutate, packet_slab_neighbour.c:119-152 */
+	const uint32_t pos = target;
+	walk_window(w, c, b.slab, lane);
+	const mgl_pk first = walk_slab_at(w, pos);
+	mgl_pk m_first = first, m_second = 0;
+	bool second_set = false, mutated = false;
+	if (pos + 1 < c.n && (nbr_draw(rng) % 2u) == 0) {
+		const mgl_pk second = uni64(b.slab[pos + 1]);
+		const uint32_t ft = mgl_pk_type(first), flen = mgl_pk_len(first);
+		const uint32_t st = mgl_pk_type(second), slen = mgl_pk_len(second), sdist = mgl_pk_dist(second);
+		if ((ft == MGL_LONG_REP || ft == MGL_MATCH) && flen > 2) {
+			m_second = mgl_pack(ft, mgl_pk_dist(first), flen - 1);
+			m_first = MGL_PK_LITERAL;
+			journal_set(jn, pos, first, m_first, lane);
+			journal_set(jn, pos + 1, second, m_second, lane);
+			second_set = true; mutated = true;
+		} else if ((ft == MGL_LITERAL || ft == MGL_SHORT_REP) && (st == MGL_MATCH || st == MGL_LONG_REP)) {
+			uint32_t rep_start = pos - (st == MGL_LONG_REP ? mgl_dist_at(&w.st, sdist) : sdist);
+			if (slen < MGL_MAX_MATCH && rep_start > 0 && rep_start <= pos &&
+			    walk_byte_at(w, pos) == c.data[rep_start - 1]) {
+				m_first = mgl_pack(st, sdist, slen + 1);
+				journal_set(jn, pos, first, m_first, lane);
+				mutated = true;
+			}
+		}
+	}
+	if (!mutated) {
+		mgl_pk picked;
+		if (!pick_from_top_k(c, w, probs, T, lencost, first, false, rng, lane, &picked)) {
+			if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+			return;
+		}
+		m_first = picked;
+		journal_set(jn, pos, first, m_first, lane);
+	}
+	walk_packet<true>(w, c, probs, T, mgl_pk_type(m_first), mgl_pk_dist(m_first), mgl_pk_len(m_first), lane); /* :169 */
+
+	/* repair_remaining_packets, packet_slab_neighbour.c:82-117 */
+	uint32_t count = 0, guard = 0;
+	while (w.st.pos < c.n && !jn.overflow) {
+		if (++guard > c.n) break;
+		count++;
+		const uint32_t p = w.st.pos;
+		walk_window(w, c, b.slab, lane);
+		const mgl_pk old = (second_set && p == pos + 1) ? m_second : walk_slab_at(w, p);
+		mgl_pk pk = old;
+		uint32_t type = mgl_pk_type(pk);
+		if (type == MGL_SHORT_REP || (type == MGL_LITERAL && count < 4)) {
+			/* for a LITERAL past the third packet the byte test cannot change anything (:91-97) */
+			const bool same = w.st.dists[0] < p && walk_byte_at(w, p) == c.data[p - w.st.dists[0] - 1];
+			if (same) { if (count < 4) pk = MGL_PK_SHORT_REP; }
+			else pk = MGL_PK_LITERAL;
+		}
+		type = mgl_pk_type(pk);
+		if (type == MGL_LONG_REP) {
+			const uint32_t len = mgl_pk_len(pk);
+			uint32_t idx = mgl_pk_dist(pk);
+			bool ok = long_rep_ok(c, w, idx, len, lane);
+			for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, w, idx, len, lane); }
+			pk = mgl_pack(MGL_LONG_REP, idx, len);
+			if (!ok) {
+				const bool best = (nbr_draw(rng) % 4u) == 0;
+				mgl_pk picked;
+				if (pick_from_top_k(c, w, probs, T, lencost, pk, best, rng, lane, &picked)) pk = picked;
+			}
+		}
+		if (pk != old) {
+			const mgl_pk base_old = (second_set && p == pos + 1) ? uni64(b.slab[p]) : old;
+			journal_set(jn, p, base_old, pk, lane);
+		}
+		walk_packet<true>(w, c, probs, T, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), lane);
+	}
+
+	const uint64_t total = base_cum + wave_sum64(w.acc);
+	wave_sync();
+	if (jn.overflow) {
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; }
+		return;
+	}
+	/* journal out: entries whose final value equals the base value are dropped */
+	uint32_t nd = 0;
+	for (uint32_t i = 0; i < jn.count; i++) {
+		if (jn.old[i] == jn.neu[i]) continue;
+		if (lane == 0) {
+			out.dpos[(size_t)j * MGL_MAX_DIFFS + nd] = jn.pos[i];
+			out.dold[(size_t)j * MGL_MAX_DIFFS + nd] = jn.old[i];
+			out.dnew[(size_t)j * MGL_MAX_DIFFS + nd] = jn.neu[i];
+		}
+		nd++;
+	}
+	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = w.packets - first_packet; }
+}
+
+/* ================================================================== k_decide */
+/* Best-of-K + the accept rule of main.c:86-96, then the winner's
+ * journal is applied to the base slab.  One block. */
+__global__ void __launch_bounds__(256) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, uint32_t K, uint64_t seed,
+                                                uint64_t iters_per_epoch, uint64_t sqrt_thresh)
+{
+	__shared__ uint64_t s_key[256];
+	__shared__ uint64_t s_cnt[256 * 2];
+	__shared__ uint32_t s_winner;
+	const uint32_t tid = threadIdx.x;
+	uint64_t best = MGL_INVALID_COST, valid = 0, walked = 0;
+	for (uint32_t j = tid; j < K; j += 256) {
+		const uint64_t cst = out.cost[j];
+		if (cst != MGL_INVALID_COST) {
+			valid++; walked += out.walked[j];
+			const uint64_t key = (cst << 20) | j;
+			best = key < best ? key : best;
+		}
+	}
+	s_key[tid] = best; s_cnt[tid] = valid; s_cnt[256 + tid] = walked;
+	__syncthreads();
+	for (uint32_t o = 128; o > 0; o >>= 1) {
+		if (tid < o) {
+			s_key[tid] = s_key[tid + o] < s_key[tid] ? s_key[tid + o] : s_key[tid];
+			s_cnt[tid] += s_cnt[tid + o];
+			s_cnt[256 + tid] += s_cnt[256 + tid + o];
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		const uint64_t gstep = ctl->gstep, i = ctl->iter;
+		const uint64_t bkey = s_key[0];
+		uint32_t winner = ~0u;
+		if (bkey != MGL_INVALID_COST) {
+			const uint64_t bcost = bkey >> 20;
+			const uint64_t key = mgl_rng_key(seed, gstep, 0xFFFFFFFFu);
+			const uint64_t m = i * i + 1 + (uint64_t)ctl->phase * iters_per_epoch / 2;
+			const bool transition = ((uint64_t)mgl_rng_draw(key, 0) % m) < sqrt_thresh;
+			if (ctl->cur_cost == 0 || bcost < ctl->cur_cost) winner = (uint32_t)(bkey & 0xFFFFFu);
+			else if (transition) {
+				const uint32_t jr = mgl_rng_draw(key, 1) % K;
+				if (out.cost[jr] != MGL_INVALID_COST) winner = jr;
+			}
+		}
+		ctl->evals += s_cnt[0];
+		ctl->failed += K - s_cnt[0];
+		ctl->packets_eval += s_cnt[256];
+		ctl->gstep = gstep + 1;
+		ctl->iter = i + 1;
+		ctl->winner = winner;
+		ctl->accepted_flag = winner != ~0u;
+		ctl->copy_best_flag = 0;
+		if (winner != ~0u) {
+			ctl->accepted++;
+			ctl->cur_cost = out.cost[winner];
+			ctl->dirty_pos = out.dpos[(size_t)winner * MGL_MAX_DIFFS];
+			if (ctl->best_cost == 0 || ctl->cur_cost < ctl->best_cost) {
+				ctl->best_cost = ctl->cur_cost;
+				ctl->copy_best_flag = 1;
+				ctl->improved++;
+			}
+		}
+		s_winner = winner;
+	}
+	__syncthreads();
+	const uint32_t winner = s_winner;
+	if (winner == ~0u) return;
+	const uint32_t nd = out.ndiffs[winner];
+	if (tid < nd) b.slab[out.dpos[(size_t)winner * MGL_MAX_DIFFS + tid]] = out.dnew[(size_t)winner * MGL_MAX_DIFFS + tid];
+}
+
+/* main.c:91 -- the new best slab (after the journal has been applied) */
+__global__ void k_copy_best(const Control* ctl, const mgl_pk* slab, mgl_pk* best, uint32_t n)
+{
+	if (!ctl->copy_best_flag) return;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) best[i] = slab[i];
+}
+
+/* ================================================================== hooks & layout */
+
+/* 12-byte reference records (lzma_packet.h:13-17) <-> packed 8-byte entries */
+__global__ void k_import(const uint32_t* aos /* 3 dwords per record */, mgl_pk* slab, uint32_t n)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t t = aos[3 * i] & 0xFFu, d = aos[3 * i + 1], l = aos[3 * i + 2] & 0xFFFFu;
+		slab[i] = mgl_pack(t, d, l);
+	}
+}
+__global__ void k_export(const mgl_pk* slab, uint32_t* aos, uint32_t n)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const mgl_pk p = slab[i];
+		aos[3 * i] = mgl_pk_type(p); aos[3 * i + 1] = mgl_pk_dist(p); aos[3 * i + 2] = mgl_pk_len(p);
+	}
+}
+__global__ void k_fill_literal(mgl_pk* slab, uint32_t n)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slab[i] = MGL_PK_LITERAL;
+}
+
+/* top-K at an arbitrary on-walk position of a (scratch) base; list written worst first */
+__global__ void __launch_bounds__(64) k_topk_probe(DevCtx c, BaseView b, uint32_t position, mgl_pk* out_pk, uint64_t* out_cost,
+                                                   uint32_t* out_count)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	uint16_t* probs = (uint16_t*)(smem + 4096);
+	uint32_t* lencost = (uint32_t*)(smem + 4096 + (size_t)b.ckpt_elems * 2);
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t i = lane; i < 2048; i += 64) T[i] = c.cost_tbl[i];
+	wave_sync();
+	if (position >= c.n || !((b.onwalk[position >> 6] >> (position & 63u)) & 1ull)) {
+		if (lane == 0) *out_count = ~0u;
+		return;
+	}
+	Walk w;
+	ckpt_load(b, c, position >> MGL_CKPT_SHIFT, probs, w, lane);
+	while (w.st.pos < position) {
+		walk_window(w, c, b.slab, lane);
+		const mgl_pk pk = walk_slab_at(w, w.st.pos);
+		walk_packet<true>(w, c, probs, T, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), lane);
+	}
+	walk_window(w, c, b.slab, lane);
+	TopK t;
+	topk_find(t, c, w, probs, T, lencost, walk_slab_at(w, position), lane);
+	if (lane < t.count) {
+		const uint32_t o = t.count - 1 - lane; /* worst first */
+		out_pk[o] = topk_packet(t.key, position);
+		out_cost[o] = t.key >> 44;
+	}
+	if (lane == 0) *out_count = t.count;
+}
+
+/* substring_enumerator_for_each, one thread, reference callback order (parity hook) */
+__global__ void k_substrings(DevCtx c, uint32_t pos, uint32_t max_len, uint32_t* offs, uint32_t* lens, uint32_t cap,
+                             uint32_t* count)
+{
+	uint32_t k = 0;
+	if (pos != 0 && pos != c.n - 1 && pos < c.n) {
+		const uint32_t bg = ((uint32_t)c.data[pos] << 8) | c.data[pos + 1];
+		for (uint32_t i = c.bucket_off[bg]; i < c.bucket_off[bg + 1]; i++) {
+			const uint32_t q = c.bucket_pos[i];
+			if (q >= pos) break;
+			if (pos - q - 1 >= c.dict_limit) continue;
+			if (k < cap) { offs[k] = q; lens[k] = 2; }
+			k++;
+			for (uint32_t j = 2; j < max_len && j + pos < c.n; j++) {
+				if (c.data[pos + j] != c.data[q + j]) break;
+				if (k < cap) { offs[k] = q; lens[k] = j + 1; }
+				k++;
+			}
+		}
+	}
+	*count = k;
+}

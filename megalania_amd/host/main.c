@@ -1,0 +1,109 @@
+/*
+ * megalania-hip -- command-line driver in C, the GPU-path counterpart of the reference's
+ * main.c:28-128: `megalania-hip [options] <file>` writes an LZMA-alone stream to stdout and
+ * progress to stderr.  Host code only calls the C ABI (include/megalania_hip.h) and emits
+ * the best slab through EncoderInterface / OutputInterface like main.c:110-119.
+ *
+ * Schedule (main.c:64-77): `phases` x `epochs` epochs; phase 0 epochs start from an
+ * all-literal slab, later phases from the best slab so far.  The reference runs N (= file
+ * size) single-neighbour iterations per epoch; here an epoch is ceil(N / K) steps of K
+ * neighbours, i.e. the same number of neighbour evaluations.  Defaults are the reference's
+ * (3 x 200) and, like the reference, take a very long time on anything but tiny inputs:
+ * use --epochs / --steps to bound the run.
+ */
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "mgl_host.h"
+
+static void usage(const char* argv0)
+{
+	fprintf(stderr,
+	        "usage: %s [--neighbours K] [--epochs E] [--phases P] [--steps S] [--seed N]\n"
+	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M] filename\n", argv0);
+}
+
+int main(int argc, char** argv)
+{
+	mgl_sa_config cfg;
+	memset(&cfg, 0, sizeof cfg);
+	cfg.seed = 1673551; /* main.c:68 */
+	cfg.neighbours_per_step = 4096;
+	cfg.top_k = 20;     /* main.c:49 */
+	mgl_properties props = { 0, 0, 0 }; /* main.c:45 */
+	unsigned epochs = 200, phases = 3;  /* main.c:66,69 */
+	unsigned long long steps_override = 0;
+	const char* filename = NULL;
+	for (int i = 1; i < argc; i++) {
+		const char* a = argv[i];
+		const char* v = i + 1 < argc ? argv[i + 1] : NULL;
+		if (a[0] != '-') { filename = a; continue; }
+		if (!v) { usage(argv[0]); return -1; }
+		if (!strcmp(a, "--neighbours")) cfg.neighbours_per_step = (uint32_t)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--epochs")) epochs = (unsigned)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--phases")) phases = (unsigned)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--steps")) steps_override = strtoull(v, NULL, 0);
+		else if (!strcmp(a, "--seed")) cfg.seed = strtoull(v, NULL, 0);
+		else if (!strcmp(a, "--lc")) props.lc = (uint8_t)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--lp")) props.lp = (uint8_t)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--pb")) props.pb = (uint8_t)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--device")) cfg.device = (int32_t)strtol(v, NULL, 0);
+		else if (!strcmp(a, "--max-scan")) cfg.max_bucket_scan = (uint32_t)strtoul(v, NULL, 0);
+		else { usage(argv[0]); return -1; }
+		i++;
+	}
+	if (!filename) { usage(argv[0]); return -1; }
+
+	int fd = open(filename, O_RDONLY);
+	if (fd < 0) { fprintf(stderr, "Error: could not open %s\n", filename); return -1; }
+	struct stat sb;
+	if (fstat(fd, &sb) < 0) { fprintf(stderr, "Error: could not stat %s\n", filename); close(fd); return -1; }
+	const size_t file_size = (size_t)sb.st_size;
+	if (file_size == 0) { close(fd); return 0; } /* main.c:40-42 */
+	const uint8_t* file_data = (const uint8_t*)mmap(NULL, file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	if (file_data == MAP_FAILED) { fprintf(stderr, "Error: could not map %s\n", filename); close(fd); return -1; }
+
+	if (mgl_device_count() < 1) {
+		fprintf(stderr, "Error: no HIP device found; this program has no CPU search path\n");
+		return -1;
+	}
+	cfg.iters_per_epoch = file_size;
+	mgl_sa* sa = mgl_sa_create(file_data, file_size, props, &cfg);
+	if (sa == NULL) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+
+	unsigned long long steps_per_epoch = (file_size + cfg.neighbours_per_step - 1) / cfg.neighbours_per_step;
+	if (steps_override) steps_per_epoch = steps_override;
+	for (unsigned phase = 0; phase < phases; phase++) {
+		for (unsigned epoch = 0; epoch < epochs; epoch++) {
+			if (mgl_sa_begin_epoch(sa, phase, phase != 0) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+			mgl_sa_stats st;
+			if (mgl_sa_run(sa, steps_per_epoch, &st) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+			/* main.c:97-99: 18 = 13 header bytes + 5 flush bytes, 16384 = 2048 * 8 */
+			fprintf(stderr, "current file size: %f\tbest: %f\tstep: %u\tepoch: %04u\t%.0f evals/s\n",
+			        18 + st.current_cost / 16384.f, 18 + st.best_cost / 16384.f, phase + 1, epoch,
+			        st.gpu_ms_total > 0 ? st.evaluations / (st.gpu_ms_total * 1e-3) : 0.0);
+		}
+	}
+
+	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
+	uint64_t best = 0;
+	if (packets_best == NULL || mgl_sa_best(sa, packets_best, &best) != MGL_OK) {
+		fprintf(stderr, "Error: could not fetch the best slab: %s\n", mgl_last_error());
+		return -1;
+	}
+	mgl_sa_destroy(sa);
+
+	OutputInterface output;
+	mgl_file_output_new(&output, stdout);
+	if (!mgl_emit_stream(file_data, file_size, props, packets_best, &output)) return -1;
+	fflush(stdout);
+	free(packets_best);
+	munmap((void*)file_data, file_size);
+	close(fd);
+	return 0;
+}

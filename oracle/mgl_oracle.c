@@ -82,6 +82,7 @@ size_t orc_num_probs(const orc_ctx* c) { return c->L.total; }
 /* ref: encoder_interface.h:9-13 -- two callbacks; here a tagged struct. */
 typedef struct {
 	int kind; /* 0 perplexity, 1 range coder */
+	int readonly; /* cost only: leave the probabilities untouched */
 	uint64_t perp;
 	/* range coder, ref: range_encoder.c:10-16 */
 	uint64_t low;
@@ -125,6 +126,7 @@ static inline void put_bit(orc_sink* s, uint16_t* prob, unsigned bit)
 		if (bit) { s->low += bound; s->range -= bound; } else { s->range = bound; }
 		while ((s->range & 0xFF000000u) == 0) { s->range <<= 8; rc_shift_low(s); }
 	}
+	if (s->readonly) return;
 	if (bit) v -= v >> 5; else v += (2048 - v) >> 5;
 	*prob = (uint16_t)v;
 }
@@ -438,10 +440,11 @@ static void topk_offer(void* ud, orc_packet pk, uint64_t seq)
 	topk* t = (topk*)ud;
 	if (pk_eq(pk, t->incumbent)) return; /* :99-101 */
 	const orc_ctx* c = t->c;
-	memcpy(t->scratch, t->st->p, sizeof(uint16_t) * c->L.total);
+	/* the reference copies the whole 5 280-byte state per candidate (:103); no context occurs
+	 * twice inside one packet, so costing against the shared model read-only is identical */
 	orc_state tmp = *t->st;
-	tmp.p = t->scratch;
 	orc_sink s = { 0 };
+	s.readonly = 1;
 	encode_packet(c, &tmp, &s, pk);
 	topk_entry ent = { pk, (uint32_t)(s.perp / (tmp.pos - t->st->pos)), seq };
 	if (t->mode == ORC_TOPK_REF) {
@@ -748,6 +751,7 @@ int orc_sa_iters(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_i
 }
 
 /* ---------------------------------------------------------------- batched semantics */
+#define ORC_MAX_JOURNAL 64
 static uint64_t mix64(uint64_t z)
 {
 	z += 0x9E3779B97F4A7C15ull;
@@ -799,6 +803,17 @@ int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, ui
 	free(on);
 	uint64_t total = 0;
 	int ok = generate_at(&g, slab, target, 0, 0, &jn, &total, probs);
+	/* the device journal holds ORC_MAX_JOURNAL distinct positions; a neighbour that needs
+	 * more is dropped as a failed generate */
+	if (ok) {
+		size_t distinct = 0;
+		for (size_t i = 0; i < jn.count; i++) {
+			int seen = 0;
+			for (size_t q = 0; q < i && !seen; q++) seen = jn.d[q].position == jn.d[i].position;
+			distinct += !seen;
+		}
+		if (distinct > ORC_MAX_JOURNAL) ok = 0;
+	}
 	if (cost) *cost = ok ? total : ~0ull;
 	/* compact the journal: first old value per position + final value, drop no-ops */
 	size_t nd = 0;

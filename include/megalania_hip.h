@@ -71,7 +71,10 @@ typedef struct {
 	uint32_t flags;               /* MGL_F_* */
 } mgl_sa_config;
 
-#define MGL_F_TIMING 1u /* record HIP events around every kernel launch of mgl_sa_run */
+#define MGL_F_TIMING 1u   /* record HIP events around every kernel launch of mgl_sa_run */
+#define MGL_F_FULLWALK 2u /* cost every neighbour by walking the slab to the end (the simple,
+                             slow engine) instead of incrementally against the base chains;
+                             both engines return identical numbers */
 
 typedef struct {
 	uint64_t steps;          /* SA steps executed by this call */
@@ -143,6 +146,9 @@ int mgl_substrings(mgl_sa* sa, size_t pos, size_t max_len, uint32_t* offsets, ui
  * generate.  diffs (nullable): diff_cap entries per neighbour, ndiffs[j] valid ones. */
 int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* diffs,
                    uint32_t* ndiffs, size_t diff_cap);
+/* Test hook: raw copy of one of the incremental engine's base structures (selector in
+ * mgl_api.hip); *bytes receives the size even when the buffer is too small. */
+int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes);
 /* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the
  * step's own stream (accept decision). */
 uint32_t mgl_rng_draw_at(uint64_t seed, uint64_t step, uint32_t j, uint32_t n);

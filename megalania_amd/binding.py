@@ -23,11 +23,12 @@ assert PACKET.itemsize == 12 and DIFF.itemsize == 28
 LITERAL, MATCH, SHORT_REP, LONG_REP = 1, 2, 3, 4
 INVALID_COST = (1 << 64) - 1
 F_TIMING = 1
+F_FULLWALK = 2
 
 HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
     "mgl_sa_set_slab", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
-    "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at",
+    "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump",
 ]
 HOST_SYMBOLS = [
     "mgl_lzma_state_init", "mgl_lzma_state_free", "mgl_lzma_encode_packet", "mgl_lzma_encode_header",
@@ -98,6 +99,7 @@ def hip_lib():
         L.mgl_substrings.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
         L.mgl_neighbours.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mgl_debug_dump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mgl_rng_draw_at.restype = C.c_uint32
         L.mgl_rng_draw_at.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         _hip = L
@@ -148,7 +150,7 @@ class SA:
     """One mgl_sa handle = one SA chain resident on one GPU."""
 
     def __init__(self, data: bytes, neighbours_per_step=4096, seed=1673551, top_k=20, lc=0, lp=0, pb=0,
-                 dict_limit=0, max_bucket_scan=0, iters_per_epoch=0, device=0, timing=False):
+                 dict_limit=0, max_bucket_scan=0, iters_per_epoch=0, device=0, timing=False, fullwalk=False):
         self.L = hip_lib()
         if self.L.mgl_device_count() < 1:
             raise MglError("no HIP device visible: the search path has no CPU implementation")
@@ -157,7 +159,7 @@ class SA:
         self.K = neighbours_per_step
         self.props = Properties(lc, lp, pb)
         self.cfg = Config(seed, neighbours_per_step, top_k, dict_limit, max_bucket_scan, iters_per_epoch, device,
-                          F_TIMING if timing else 0)
+                          (F_TIMING if timing else 0) | (F_FULLWALK if fullwalk else 0))
         self.h = self.L.mgl_sa_create(_ptr(self.data), self.n, self.props, C.byref(self.cfg))
         if not self.h:
             raise MglError(self.L.mgl_last_error().decode())
@@ -232,6 +234,14 @@ class SA:
         self._chk(self.L.mgl_substrings(self.h, pos, max_len, _ptr(offs), _ptr(lens), cap, C.byref(cnt)))
         assert cnt.value <= cap
         return offs[: cnt.value].copy(), lens[: cnt.value].copy()
+
+    def debug_dump(self, what: int, dtype) -> np.ndarray:
+        need = C.c_size_t(0)
+        probe = np.zeros(1, dtype=np.uint8)
+        self.L.mgl_debug_dump(self.h, what, _ptr(probe), 0, C.byref(need))
+        out = np.zeros(max(1, need.value), dtype=np.uint8)
+        self._chk(self.L.mgl_debug_dump(self.h, what, _ptr(out), need.value, C.byref(need)))
+        return out[: need.value].view(dtype)
 
     def neighbours(self, global_step: int, want_diffs=True, diff_cap=64):
         costs = np.zeros(self.K, dtype=np.uint64)

@@ -3,6 +3,7 @@
  * Owns all device memory; one HIP stream per handle; no host thread is created.
  */
 #include "mgl_kernels.hip"
+#include "mgl_kernels2.hip"
 #include "../../include/megalania_hip.h"
 
 #include <math.h>
@@ -72,6 +73,12 @@ struct mgl_sa {
 	uint32_t sub_cap;
 	uint64_t sqrt_thresh;
 	uint32_t per_wave_bytes, waves_per_block, nbr_lds, walk_lds;
+	/* incremental path (mgl_kernels2.hip) */
+	bool incremental;
+	Base2 b2;
+	uint32_t* d_todo;       /* [0] = count, [1..K] = neighbour indices for the full-walk fallback */
+	uint32_t per_wave2, waves_per_block2, nbr2_lds, build_lds;
+	size_t b2_bytes;
 	hipEvent_t ev_begin, ev_end;
 	std::vector<hipEvent_t> ev_pool;
 };
@@ -111,12 +118,35 @@ static int launch_rebuild(mgl_sa* sa, BaseMem& b, int from_dirty, uint64_t* cum,
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
+/* (re)derive everything that hangs off the current base slab */
+static int rebuild_base(mgl_sa* sa, int after_accept)
+{
+	if (!sa->incremental) return launch_rebuild(sa, sa->base, after_accept, nullptr, nullptr);
+	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, after_accept);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
 static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
+	if (!sa->incremental) {
+		const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
+		hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
+		                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
+		                   (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+		HIPCHK(hipGetLastError());
+		return MGL_OK;
+	}
+	HIPCHK(hipMemsetAsync(sa->d_todo, 0, sizeof(uint32_t), sa->stream));
+	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
+	hipLaunchKernelGGL(k_neighbours2, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx, sa->b2,
+	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1,
+	                   sa->d_todo);
+	/* neighbours that did not fit the LDS change lists: exact full walk from byte 0 */
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
-	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes);
+	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
+	                   (const uint32_t*)(sa->d_todo + 1), (const uint32_t*)sa->d_todo);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -148,6 +178,9 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
+	dfree(sa->b2.sp0); dfree(sa->b2.sp1); dfree(sa->b2.sp2); dfree(sa->b2.sp_state); dfree(sa->b2.ck_probs);
+	dfree(sa->b2.ch_off); dfree(sa->b2.ch_len); dfree(sa->b2.ch_cap); dfree(sa->b2.ch_pos); dfree(sa->b2.ch_ev);
+	dfree(sa->b2.pool_top); dfree(sa->d_todo);
 	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
 	for (hipEvent_t e : sa->ev_pool) (void)hipEventDestroy(e);
 	if (sa->ev_begin) (void)hipEventDestroy(sa->ev_begin);
@@ -222,13 +255,53 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipFuncSetAttribute((const void*)k_rebuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->walk_lds));
 	HIPCHK(hipFuncSetAttribute((const void*)k_topk_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->walk_lds));
 
+	/* incremental path: bitmaps, special-state records, dense checkpoints, event chains */
+	sa->incremental = !(sa->cfg.flags & MGL_F_FULLWALK);
+	if (sa->incremental) {
+		Base2& b = sa->b2;
+		memset(&b, 0, sizeof b);
+		b.slab = sa->base.v.slab;
+		b.onwalk = sa->base.v.onwalk;
+		b.nw0 = (uint32_t)(((size_t)n + 63) / 64);
+		b.nw1 = (b.nw0 + 63) / 64;
+		b.nw2 = (b.nw1 + 63) / 64;
+		b.nck = b.nw0;
+		b.ck_elems = ckpt_elems;
+		b.pool_cap = (uint32_t)(14 * n + (size_t)L.total * 40 + 4096);
+		size_t bytes = 0;
+		HIPCHK(hipMalloc(&b.sp0, sizeof(uint64_t) * (b.nw0 + 64))); bytes += sizeof(uint64_t) * (b.nw0 + 64);
+		HIPCHK(hipMalloc(&b.sp1, sizeof(uint64_t) * (b.nw1 + 64)));
+		HIPCHK(hipMalloc(&b.sp2, sizeof(uint64_t) * (b.nw2 + 64)));
+		HIPCHK(hipMemset(b.sp0, 0, sizeof(uint64_t) * (b.nw0 + 64)));
+		HIPCHK(hipMemset(b.sp1, 0, sizeof(uint64_t) * (b.nw1 + 64)));
+		HIPCHK(hipMemset(b.sp2, 0, sizeof(uint64_t) * (b.nw2 + 64)));
+		HIPCHK(hipMalloc(&b.sp_state, sizeof(uint32_t) * 8 * n)); bytes += sizeof(uint32_t) * 8 * n;
+		HIPCHK(hipMalloc(&b.ck_probs, sizeof(uint16_t) * (size_t)b.nck * ckpt_elems)); bytes += sizeof(uint16_t) * (size_t)b.nck * ckpt_elems;
+		HIPCHK(hipMalloc(&b.ch_off, sizeof(uint32_t) * ckpt_elems));
+		HIPCHK(hipMalloc(&b.ch_len, sizeof(uint32_t) * ckpt_elems));
+		HIPCHK(hipMalloc(&b.ch_cap, sizeof(uint32_t) * ckpt_elems));
+		HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * (size_t)b.pool_cap)); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
+		HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * (size_t)b.pool_cap)); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
+		HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
+		HIPCHK(hipMalloc(&sa->d_todo, sizeof(uint32_t) * (K + 1)));
+		HIPCHK(hipMemset(sa->d_todo, 0, sizeof(uint32_t) * (K + 1)));
+		sa->b2_bytes = bytes;
+		sa->per_wave2 = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) + MGL_UCTX_CAP * 2u;
+		sa->waves_per_block2 = 4;
+		while (sa->waves_per_block2 > 1 && 4096u + sa->waves_per_block2 * sa->per_wave2 > 160u * 1024u) sa->waves_per_block2--;
+		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
+		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
+	}
+
 	sa->sqrt_thresh = ceil_sqrt_u64(sa->cfg.iters_per_epoch);
 
 	/* packet_slab_new: all-literal current and best slabs */
 	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
 	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->d_best, sa->ctx.n);
 	HIPCHK(hipGetLastError());
-	int rc = launch_rebuild(sa, sa->base, 0, nullptr, nullptr);
+	int rc = rebuild_base(sa, 0);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	return MGL_OK;
@@ -287,7 +360,7 @@ extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 	if (rc) return rc;
 	c.iter = 0; c.cur_cost = 0; c.phase = phase; c.accepted_flag = 0; c.copy_best_flag = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
-	if ((rc = launch_rebuild(sa, sa->base, 0, nullptr, nullptr))) return rc;
+	if ((rc = rebuild_base(sa, 0))) return rc;
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	return MGL_OK;
 }
@@ -302,7 +375,7 @@ extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
 	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
-	if ((rc = launch_rebuild(sa, sa->base, 0, nullptr, nullptr))) return rc;
+	if ((rc = rebuild_base(sa, 0))) return rc;
 	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
 	if (c.error_flags) return fail(MGL_EINVAL, "mgl_sa_set_slab: slab is not a valid parse");
 	return MGL_OK;
@@ -340,7 +413,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 		HIPCHK(hipGetLastError());
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
-		if ((rc = launch_rebuild(sa, sa->base, 1, nullptr, nullptr))) return rc;
+		if ((rc = rebuild_base(sa, 1))) return rc;
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 	}
 	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
@@ -543,5 +616,35 @@ extern "C" int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs,
 			d->new_packet.type = (uint8_t)mgl_pk_type(w); d->new_packet.dist = mgl_pk_dist(w); d->new_packet.len = (uint16_t)mgl_pk_len(w);
 		}
 	}
+	return MGL_OK;
+}
+
+/* test hook: raw copies of the incremental path's base structures */
+extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes)
+{
+	if (!sa || !out || !bytes) return fail(MGL_EINVAL, "null argument");
+	if (!sa->incremental) return fail(MGL_EINVAL, "mgl_debug_dump: handle runs the full-walk engine");
+	HIPCHK(hipSetDevice(sa->device));
+	HIPCHK(hipStreamSynchronize(sa->stream));
+	const Base2& b = sa->b2;
+	const void* src = nullptr;
+	size_t sz = 0;
+	uint32_t top = 0;
+	HIPCHK(hipMemcpy(&top, b.pool_top, sizeof top, hipMemcpyDeviceToHost));
+	switch (what) {
+	case 0: src = b.ch_off; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
+	case 1: src = b.ch_len; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
+	case 2: src = b.ch_pos; sz = sizeof(uint32_t) * (size_t)top; break;
+	case 3: src = b.ch_ev; sz = sizeof(uint16_t) * (size_t)top; break;
+	case 4: src = b.onwalk; sz = sizeof(uint64_t) * b.nw0; break;
+	case 5: src = b.sp0; sz = sizeof(uint64_t) * b.nw0; break;
+	case 6: src = b.sp_state; sz = sizeof(uint32_t) * 8 * (size_t)sa->n; break;
+	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
+	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
+	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
+	}
+	*bytes = sz;
+	if (sz > cap_bytes) return fail(MGL_ERANGE, "mgl_debug_dump: buffer too small");
+	HIPCHK(hipMemcpy(out, src, sz, hipMemcpyDeviceToHost));
 	return MGL_OK;
 }

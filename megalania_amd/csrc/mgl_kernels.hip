@@ -417,15 +417,22 @@ __device__ __forceinline__ bool long_rep_ok(const DevCtx& c, const Walk& w, uint
 }
 
 /* One wavefront = one neighbour of the base slab (packet_slab_neighbour.c:154-173). */
+/* todo != nullptr: only the neighbours listed there are evaluated (the ones the incremental
+ * kernel could not fit), walking from byte 0 instead of from a prefix checkpoint. */
 __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const Control* ctl, uint64_t seed,
-                                                    uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes)
+                                                    uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
+                                                    const uint32_t* todo, const uint32_t* todo_count)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	const uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	if (todo) {
+		if (j >= *todo_count) return;
+		j = uni(todo[j]);
+	}
 	if (j >= K) return;
 	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
 	uint16_t* probs = (uint16_t*)mine;
@@ -465,7 +472,14 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 
 	/* prefix: nearest checkpoint, then the unchanged packets up to the target (:165) */
 	Walk w;
-	const uint64_t base_cum = ckpt_load(b, c, target >> MGL_CKPT_SHIFT, probs, w, lane);
+	uint64_t base_cum = 0;
+	if (todo) {
+		for (uint32_t i = lane; i < b.ckpt_elems; i += 64) probs[i] = MGL_PROB_INIT;
+		walk_reset(w);
+		wave_sync();
+	} else {
+		base_cum = ckpt_load(b, c, target >> MGL_CKPT_SHIFT, probs, w, lane);
+	}
 	const uint32_t first_packet = w.packets;
 	while (w.st.pos < target) {
 		walk_window(w, c, b.slab, lane);

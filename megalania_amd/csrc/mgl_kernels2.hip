@@ -1,0 +1,611 @@
+/*
+ * mgl_kernels2.hip -- the incremental neighbour path.
+ *
+ *   k_build        one wavefront walks the base slab twice: (1) bitmaps, per-special state
+ *                  records, per-context event counts -> chain offsets; (2) fills the chains
+ *                  (position, bit, probability before) and the dense checkpoints, totals the cost
+ *   k_neighbours2  one wavefront per neighbour.  Work is proportional to the *changed window*,
+ *                  not to the file: walk state at the target from the special records, mutate
+ *                  (top-K needs the model at the target: dense checkpoint + <= 64 bytes of replay),
+ *                  then a two-pointer walk over the neighbour's and the base's packets that stops
+ *                  when position, ctx_state and rep distances agree again; identical packets
+ *                  cancel, runs of plain literals are skipped through the special bitmap.  The
+ *                  inserted / removed events are then priced per probability context against
+ *                  the base chains until each perturbed probability re-joins its base trajectory.
+ *                  The result is the neighbour's exact total (u64) -- the same number
+ *                  packet_slab_neighbour_generate (packet_slab_neighbour.c:154-173) would return.
+ */
+#include "mgl_base2.h"
+
+/* ================================================================== k_build */
+
+struct BitAcc {
+	uint32_t word;
+	uint64_t bits;
+};
+__device__ __forceinline__ void bitacc_move(BitAcc& a, uint64_t* arr, uint32_t new_word, uint32_t lane)
+{
+	if (new_word == a.word) return;
+	if (lane == 0) arr[a.word] = a.bits;
+	for (uint32_t z = a.word + 1 + lane; z < new_word; z += 64) arr[z] = 0;
+	a.word = new_word; a.bits = 0;
+}
+
+__global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, int check_cost)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	uint16_t* probs = (uint16_t*)(smem + 4096);
+	uint32_t* cnt = (uint32_t*)(smem + 4096 + (size_t)b.ck_elems * 2);
+	uint32_t* off = cnt + b.ck_elems;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t total = c.L.total;
+	if (check_cost && !ctl->accepted_flag) return; /* per-step rebuild: nothing moved */
+	for (uint32_t i = lane; i < 2048; i += 64) T[i] = c.cost_tbl[i];
+	for (uint32_t i = lane; i < b.ck_elems; i += 64) { cnt[i] = 0; off[i] = 0; }
+	wave_sync();
+
+	/* ---- pass 1: bitmaps, special-state records, event counts */
+	Walk w;
+	walk_reset(w);
+	BitAcc on = { 0, 0 }, sp = { 0, 0 };
+	uint32_t guard = 0;
+	while (w.st.pos < c.n) {
+		const uint32_t pos = w.st.pos;
+		if (++guard > c.n) { if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); break; }
+		bitacc_move(on, b.onwalk, pos >> 6, lane);
+		bitacc_move(sp, b.sp0, pos >> 6, lane);
+		on.bits |= 1ull << (pos & 63u);
+		walk_window(w, c, b.slab, lane);
+		const mgl_pk pk = walk_slab_at(w, pos);
+		uint32_t type = mgl_pk_type(pk), len = mgl_pk_len(pk), dist = mgl_pk_dist(pk);
+		if (type < MGL_LITERAL || type > MGL_LONG_REP || len == 0 || pos + len > c.n) {
+			type = MGL_LITERAL; len = 1; dist = 0;
+			if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
+		}
+		if (type != MGL_LITERAL) {
+			sp.bits |= 1ull << (pos & 63u);
+			if (lane < 8) {
+				const uint32_t v = lane == 0 ? w.st.ctx_state : lane == 1 ? w.st.dists[0] : lane == 2 ? w.st.dists[1]
+				                 : lane == 3 ? w.st.dists[2] : lane == 4 ? w.st.dists[3] : 0u;
+				b.sp_state[(size_t)pos * 8 + lane] = v;
+			}
+		}
+		const uint32_t byte = walk_byte_at(w, pos);
+		uint32_t match_byte = 0, prev_byte = 0;
+		if (type == MGL_LITERAL) {
+			if (w.st.ctx_state >= 7 && w.st.dists[0] < pos) match_byte = c.data[pos - w.st.dists[0] - 1];
+			if (c.L.lc > 0 && pos > 0) prev_byte = c.data[pos - 1];
+		}
+		mgl_plan pl;
+		mgl_plan_packet(&c.L, &w.st, type, dist, len, byte, match_byte, prev_byte, &pl);
+		if (lane < pl.nev) {
+			uint32_t ctx, bit;
+			mgl_plan_event(&pl, lane, &ctx, &bit);
+			cnt[ctx]++; /* contexts of one packet are distinct: no conflict */
+		}
+		mgl_advance(&w.st, type, dist, len);
+		w.packets++;
+	}
+	{
+		const uint32_t nw0 = b.nw0;
+		bitacc_move(on, b.onwalk, nw0, lane);
+		bitacc_move(sp, b.sp0, nw0, lane);
+	}
+	const uint32_t npackets = w.packets;
+	__threadfence();
+	wave_sync();
+	/* summary levels of the special bitmap */
+	for (uint32_t u = 0; u < b.nw1; u++) {
+		const uint32_t wd = u * 64 + lane;
+		const bool nz = wd < b.nw0 && b.sp0[wd] != 0;
+		const unsigned long long m = __ballot(nz);
+		if (lane == 0) b.sp1[u] = m;
+	}
+	__threadfence();
+	wave_sync();
+	for (uint32_t v = 0; v < b.nw2; v++) {
+		const uint32_t u = v * 64 + lane;
+		const bool nz = u < b.nw1 && b.sp1[u] != 0;
+		const unsigned long long m = __ballot(nz);
+		if (lane == 0) b.sp2[v] = m;
+	}
+	/* chain offsets: capacity = len + len/2 + 32 (+1 sentinel); lanes own contiguous context ranges */
+	{
+		const uint32_t per = (total + 63u) / 64u;
+		const uint32_t lo = lane * per, hi = (lo + per) < total ? (lo + per) : total;
+		uint32_t sum = 0;
+		for (uint32_t i = lo; i < hi; i++) sum += cnt[i] + (cnt[i] >> 1) + 33u;
+		uint32_t incl = sum;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+			if ((int)lane >= o) incl += t;
+		}
+		uint32_t run = incl - sum;
+		for (uint32_t i = lo; i < hi; i++) {
+			const uint32_t cap = cnt[i] + (cnt[i] >> 1) + 33u;
+			off[i] = run;
+			b.ch_off[i] = run; b.ch_len[i] = cnt[i]; b.ch_cap[i] = cap;
+			run += cap;
+		}
+		const uint32_t all = (uint32_t)__shfl((int)incl, 63, 64);
+		if (lane == 0) {
+			*b.pool_top = all;
+			if (all > b.pool_cap) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
+		}
+		if (all > b.pool_cap) return;
+	}
+	wave_sync();
+	for (uint32_t i = lane; i < b.ck_elems; i += 64) { cnt[i] = 0; probs[i] = MGL_PROB_INIT; }
+	wave_sync();
+
+	/* ---- pass 2: chains + dense checkpoints + cost */
+	walk_reset(w);
+	uint32_t next_ck = 0;
+	guard = 0;
+	while (w.st.pos < c.n) {
+		const uint32_t pos = w.st.pos;
+		if (++guard > c.n) break;
+		while (next_ck < b.nck && (next_ck << MGL_CK2_SHIFT) <= pos) {
+			uint32_t* dst = (uint32_t*)(b.ck_probs + (size_t)next_ck * b.ck_elems);
+			const uint32_t* src = (const uint32_t*)probs;
+			for (uint32_t i = lane; i < b.ck_elems / 2; i += 64) dst[i] = src[i];
+			next_ck++;
+		}
+		walk_window(w, c, b.slab, lane);
+		const mgl_pk pk = walk_slab_at(w, pos);
+		uint32_t type = mgl_pk_type(pk), len = mgl_pk_len(pk), dist = mgl_pk_dist(pk);
+		if (type < MGL_LITERAL || type > MGL_LONG_REP || len == 0 || pos + len > c.n) { type = MGL_LITERAL; len = 1; dist = 0; }
+		const uint32_t byte = walk_byte_at(w, pos);
+		uint32_t match_byte = 0, prev_byte = 0;
+		if (type == MGL_LITERAL) {
+			if (w.st.ctx_state >= 7 && w.st.dists[0] < pos) match_byte = c.data[pos - w.st.dists[0] - 1];
+			if (c.L.lc > 0 && pos > 0) prev_byte = c.data[pos - 1];
+		}
+		mgl_plan pl;
+		mgl_plan_packet(&c.L, &w.st, type, dist, len, byte, match_byte, prev_byte, &pl);
+		if (lane < pl.nev) {
+			uint32_t ctx, bit;
+			mgl_plan_event(&pl, lane, &ctx, &bit);
+			const uint32_t p = probs[ctx];
+			const uint32_t k = off[ctx] + cnt[ctx]++;
+			b.ch_pos[k] = pos;
+			b.ch_ev[k] = (uint16_t)((bit << 15) | p);
+			w.acc += T[bit ? 2048u - p : p];
+			probs[ctx] = (uint16_t)mgl_prob_update(p, bit);
+		}
+		if (lane == 0) w.acc += (uint64_t)pl.ndirect << 11;
+		mgl_advance(&w.st, type, dist, len);
+		w.packets++;
+	}
+	wave_sync();
+	/* sentinels: position = infinity, probability = the context's final value */
+	for (uint32_t i = lane; i < total; i += 64) {
+		const uint32_t k = off[i] + cnt[i];
+		b.ch_pos[k] = MGL_POS_INF;
+		b.ch_ev[k] = probs[i];
+	}
+	const uint64_t cost = wave_sum64(w.acc);
+	if (lane == 0) {
+		ctl->packets = npackets;
+		ctl->rebuild_cost = cost;
+		ctl->final_ctx_state = w.st.ctx_state;
+		ctl->final_dists[0] = w.st.dists[0]; ctl->final_dists[1] = w.st.dists[1];
+		ctl->final_dists[2] = w.st.dists[2]; ctl->final_dists[3] = w.st.dists[3];
+		if (check_cost) {
+			if (ctl->cur_cost != cost) atomicOr(&ctl->error_flags, MGL_ERR_REBUILD_MISMATCH);
+			ctl->accepted_flag = 0;
+		}
+	}
+}
+
+/* ================================================================== change lists */
+
+struct Changes {
+	uint16_t* ins_key; /* ctx | bit << 15 */
+	uint32_t* ins_pos;
+	uint16_t* rem_key; /* ctx */
+	uint32_t* rem_pos;
+	uint16_t* uctx;
+	uint32_t n_ins, n_rem; /* uniform */
+	int64_t direct;        /* (inserted - removed) direct-bit cost, uniform */
+	bool overflow;
+};
+
+/* append the events of one planned packet to the inserted (INS) or removed list */
+template <bool INS>
+__device__ __forceinline__ void changes_add(Changes& ch, const mgl_plan& pl, uint32_t pos, uint32_t lane)
+{
+	uint32_t& n = INS ? ch.n_ins : ch.n_rem;
+	if (n + pl.nev > MGL_CHG_CAP) { ch.overflow = true; return; }
+	if (lane < pl.nev) {
+		uint32_t ctx, bit;
+		mgl_plan_event(&pl, lane, &ctx, &bit);
+		if (INS) { ch.ins_key[n + lane] = (uint16_t)(ctx | (bit << 15)); ch.ins_pos[n + lane] = pos; }
+		else { ch.rem_key[n + lane] = (uint16_t)ctx; ch.rem_pos[n + lane] = pos; }
+	}
+	n += pl.nev;
+	const int64_t d = (int64_t)((uint64_t)pl.ndirect << 11);
+	ch.direct += INS ? d : -d;
+}
+
+/* Price the change lists against the base chains.  Every distinct touched context is
+ * re-simulated by one lane from its first change, merging the base chain (minus removed
+ * events) with the inserted events by position, until no change is pending and the running
+ * probability equals the base's (re-coupled), the chain ends, or `limit` is reached.
+ * Returns sum(new cost - base cost) over the simulated spans (all lanes get the value).
+ * If overlay != nullptr the probability each touched context has at `limit` is written into
+ * it (contexts that re-coupled before `limit` keep the base value already there). */
+__device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uint32_t limit, uint16_t* overlay,
+                             uint32_t lane, bool* too_many)
+{
+	const uint32_t m = ch.n_ins + ch.n_rem;
+	wave_sync();
+	/* distinct contexts, in first-appearance order */
+	uint32_t nu = 0;
+	for (uint32_t base = 0; base < m; base += 64) {
+		const uint32_t e = base + lane;
+		bool first = false;
+		uint32_t key = 0;
+		if (e < m) {
+			key = e < ch.n_ins ? (ch.ins_key[e] & 0x7FFFu) : ch.rem_key[e - ch.n_ins];
+			first = true;
+			for (uint32_t q = 0; q < e && first; q++) {
+				const uint32_t kq = q < ch.n_ins ? (ch.ins_key[q] & 0x7FFFu) : ch.rem_key[q - ch.n_ins];
+				first = kq != key;
+			}
+		}
+		const unsigned long long mask = __ballot(first);
+		const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+		const uint32_t add = (uint32_t)__popcll(mask);
+		if (nu + add > MGL_UCTX_CAP) { *too_many = true; return 0; }
+		if (first) ch.uctx[nu + rank] = (uint16_t)key;
+		nu += add;
+	}
+	wave_sync();
+	int64_t delta = 0;
+	for (uint32_t base = 0; base < nu; base += 64) {
+		if (base + lane >= nu) continue;
+		const uint32_t cx = ch.uctx[base + lane];
+		uint32_t ii = 0, ri = 0;
+		while (ii < ch.n_ins && (ch.ins_key[ii] & 0x7FFFu) != cx) ii++;
+		while (ri < ch.n_rem && ch.rem_key[ri] != cx) ri++;
+		const uint32_t ipos0 = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
+		const uint32_t rpos0 = ri < ch.n_rem ? ch.rem_pos[ri] : MGL_POS_INF;
+		const uint32_t x0 = ipos0 < rpos0 ? ipos0 : rpos0;
+		const uint32_t* cpos = b.ch_pos + b.ch_off[cx];
+		const uint16_t* cev = b.ch_ev + b.ch_off[cx];
+		uint32_t k = chain_lower_bound(cpos, b.ch_len[cx], x0);
+		uint32_t p = cev[k] & 0x7FFu;
+		bool at_limit = false;
+		for (;;) {
+			const uint32_t bpos = cpos[k];
+			const uint32_t ipos = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
+			if (ipos < bpos) {
+				if (ipos >= limit) { at_limit = true; break; }
+				const uint32_t bit = ch.ins_key[ii] >> 15;
+				delta += T[bit ? 2048u - p : p];
+				p = mgl_prob_update(p, bit);
+				ii++;
+				while (ii < ch.n_ins && (ch.ins_key[ii] & 0x7FFFu) != cx) ii++;
+				continue;
+			}
+			if (bpos == MGL_POS_INF) break;         /* chain exhausted */
+			if (bpos >= limit) { at_limit = true; break; }
+			const uint32_t ev = cev[k];
+			const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+			const bool pending = ii < ch.n_ins || ri < ch.n_rem;
+			if (!pending && p == bp) break;          /* re-coupled: identical from here on */
+			delta -= T[bb ? 2048u - bp : bp];
+			if (ri < ch.n_rem && ch.rem_pos[ri] == bpos) {
+				ri++;
+				while (ri < ch.n_rem && ch.rem_key[ri] != cx) ri++;
+			} else {
+				delta += T[bb ? 2048u - p : p];
+				p = mgl_prob_update(p, bb);
+			}
+			k++;
+		}
+		if (overlay && (at_limit || cpos[k] == MGL_POS_INF)) overlay[cx] = (uint16_t)p;
+	}
+	/* signed wave sum */
+	uint64_t u = (uint64_t)delta;
+	u = wave_sum64(u);
+	wave_sync();
+	return (int64_t)u;
+}
+
+/* ================================================================== k_neighbours2 */
+
+struct Win {
+	uint32_t base;
+	mgl_pk pk;
+	uint32_t byte;
+};
+__device__ __forceinline__ void win_cover(Win& w, const DevCtx& c, const mgl_pk* slab, uint32_t pos, uint32_t lane)
+{
+	const uint32_t base = pos & ~63u;
+	if (base != w.base) {
+		const uint32_t p = base + lane;
+		w.pk = p < c.n ? slab[p] : 0;
+		w.byte = c.data[p < c.n ? p : c.n];
+		w.base = base;
+	}
+}
+__device__ __forceinline__ mgl_pk win_pk(const Win& w, uint32_t pos) { return rdlane64(w.pk, pos - w.base); }
+__device__ __forceinline__ uint32_t win_byte(const Win& w, uint32_t pos) { return rdlane(w.byte, pos - w.base); }
+
+__device__ __forceinline__ void plan_at(const DevCtx& c, const mgl_wstate& st, uint32_t type, uint32_t dist, uint32_t len,
+                                        uint32_t byte, mgl_plan& pl)
+{
+	uint32_t match_byte = 0, prev_byte = 0;
+	if (type == MGL_LITERAL) {
+		if (st.ctx_state >= 7 && st.dists[0] < st.pos) match_byte = c.data[st.pos - st.dists[0] - 1];
+		if (c.L.lc > 0 && st.pos > 0) prev_byte = c.data[st.pos - 1];
+	}
+	mgl_plan_packet(&c.L, &st, type, dist, len, byte, match_byte, prev_byte, &pl);
+}
+
+/* The adaptive model the neighbour has at position y, in LDS: base model before the first
+ * base packet at or after y (dense checkpoint + replay of < 64 bytes of base packets), with
+ * the touched contexts overridden by their re-simulated values. */
+__device__ void model_at(const DevCtx& c, const Base2& b, Changes& ch, uint16_t* probs, const uint16_t* T, uint32_t y,
+                         uint32_t lane, bool* too_many)
+{
+	const uint32_t ck = y >> MGL_CK2_SHIFT;
+	const uint32_t* src = (const uint32_t*)(b.ck_probs + (size_t)ck * b.ck_elems);
+	uint32_t* dst = (uint32_t*)probs;
+	for (uint32_t i = lane; i < b.ck_elems / 2; i += 64) dst[i] = src[i];
+	/* first base packet start in [ck*64, y) */
+	const uint64_t bits = b.onwalk[ck] & ((y & 63u) ? ((1ull << (y & 63u)) - 1ull) : 0ull);
+	wave_sync();
+	if (bits) {
+		const uint32_t start = uni((ck << 6) + ctz64(bits));
+		Walk w;
+		walk_reset(w);
+		w.st = uni_state(base_state_at(b, start));
+		while (w.st.pos < y) {
+			walk_window(w, c, b.slab, lane);
+			const mgl_pk pk = walk_slab_at(w, w.st.pos);
+			walk_packet<true>(w, c, probs, T, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), lane);
+		}
+		wave_sync();
+	}
+	if (ch.n_ins + ch.n_rem) chain_sim(b, ch, T, y, probs, lane, too_many);
+	wave_sync();
+}
+
+/* the Walk-based helpers of the full-walk path read the input through Walk's window */
+__device__ __forceinline__ void walk_from_state(Walk& w, const mgl_wstate& st)
+{
+	walk_reset(w);
+	w.st = st;
+}
+
+__global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Control* ctl, uint64_t seed,
+                                                     uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
+                                                     uint32_t* todo, uint32_t* todo_count)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	const uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	if (j >= K) return;
+	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
+	uint16_t* probs = (uint16_t*)mine;
+	uint32_t* lencost = (uint32_t*)(mine + (size_t)b.ck_elems * 2);
+	Journal jn;
+	jn.old = (mgl_pk*)(lencost + 544);
+	jn.neu = jn.old + MGL_MAX_DIFFS;
+	jn.pos = (uint32_t*)(jn.neu + MGL_MAX_DIFFS);
+	jn.count = 0; jn.overflow = false;
+	Changes ch;
+	ch.ins_pos = jn.pos + MGL_MAX_DIFFS;
+	ch.rem_pos = ch.ins_pos + MGL_CHG_CAP;
+	ch.ins_key = (uint16_t*)(ch.rem_pos + MGL_CHG_CAP);
+	ch.rem_key = ch.ins_key + MGL_CHG_CAP;
+	ch.uctx = ch.rem_key + MGL_CHG_CAP;
+	ch.n_ins = ch.n_rem = 0; ch.direct = 0; ch.overflow = false;
+	bool too_many = false;
+
+	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
+	NbrRng rng; rng.key = mgl_rng_key(seed, gstep, j); rng.n = 0;
+
+	/* target (same rule as the full-walk path) */
+	uint32_t target;
+	{
+		uint32_t mydraw = lane < 32 ? mgl_rng_draw(rng.key, lane) % c.n : 0;
+		bool on = lane < 32 && ((b.onwalk[mydraw >> 6] >> (mydraw & 63u)) & 1ull);
+		unsigned long long m = __ballot(on);
+		if (m) {
+			int f = __ffsll((long long)m) - 1;
+			target = rdlane(mydraw, (uint32_t)f);
+			rng.n = (uint32_t)f + 1;
+		} else {
+			rng.n = 32;
+			uint32_t p = rdlane(mydraw, 31);
+			uint32_t wd = p >> 6;
+			uint64_t bits = b.onwalk[wd] & (~0ull << (p & 63u));
+			while (!bits && ++wd < b.nw0) bits = b.onwalk[wd];
+			target = uni(bits ? (wd << 6) + ctz64(bits) : 0u);
+		}
+	}
+	const uint32_t pos = target;
+	mgl_wstate nb = uni_state(base_state_at(b, pos)); /* neighbour's walk state */
+	mgl_wstate bs = nb;                               /* base's walk state */
+	Win win; win.base = 0xFFFFFFFFu; win.pk = 0; win.byte = 0;
+	Walk tw; /* scratch Walk for top-K (its window is the input window at the query position) */
+
+	/* ---- mutate, packet_slab_neighbour.c:119-152 */
+	win_cover(win, c, b.slab, pos, lane);
+	const mgl_pk first = win_pk(win, pos);
+	mgl_pk m_first = first, m_second = 0;
+	bool second_set = false, mutated = false;
+	if (pos + 1 < c.n && (nbr_draw(rng) % 2u) == 0) {
+		const mgl_pk second = uni64(b.slab[pos + 1]);
+		const uint32_t ft = mgl_pk_type(first), flen = mgl_pk_len(first);
+		const uint32_t st = mgl_pk_type(second), slen = mgl_pk_len(second), sdist = mgl_pk_dist(second);
+		if ((ft == MGL_LONG_REP || ft == MGL_MATCH) && flen > 2) {
+			m_second = mgl_pack(ft, mgl_pk_dist(first), flen - 1);
+			m_first = MGL_PK_LITERAL;
+			journal_set(jn, pos, first, m_first, lane);
+			journal_set(jn, pos + 1, second, m_second, lane);
+			second_set = true; mutated = true;
+		} else if ((ft == MGL_LITERAL || ft == MGL_SHORT_REP) && (st == MGL_MATCH || st == MGL_LONG_REP)) {
+			uint32_t rep_start = pos - (st == MGL_LONG_REP ? mgl_dist_at(&nb, sdist) : sdist);
+			if (slen < MGL_MAX_MATCH && rep_start > 0 && rep_start <= pos && win_byte(win, pos) == c.data[rep_start - 1]) {
+				m_first = mgl_pack(st, sdist, slen + 1);
+				journal_set(jn, pos, first, m_first, lane);
+				mutated = true;
+			}
+		}
+	}
+	if (!mutated) {
+		model_at(c, b, ch, probs, T, pos, lane, &too_many);
+		walk_from_state(tw, nb);
+		walk_window(tw, c, b.slab, lane);
+		mgl_pk picked;
+		if (!pick_from_top_k(c, tw, probs, T, lencost, first, false, rng, lane, &picked)) {
+			if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+			return;
+		}
+		m_first = picked;
+		journal_set(jn, pos, first, m_first, lane);
+	}
+
+	/* ---- two-pointer walk over neighbour packets (nb) and base packets (bs) */
+	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
+	uint32_t walked = 0;
+	bool first_packet = true;
+	uint32_t guard = 0;
+	while (nb.pos < c.n || bs.pos < c.n) {
+		if (ch.overflow || jn.overflow || too_many || ++guard > 4096u) { ch.overflow = true; break; }
+		if (!first_packet && nb.pos == bs.pos && count >= 3) {
+			const bool same_ctx = nb.ctx_state == bs.ctx_state;
+			const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
+			                    nb.dists[3] == bs.dists[3];
+			if (same_ctx && same_d) break; /* the rest of the file is coded identically */
+			if (same_ctx && nb.ctx_state < 7) {
+				/* plain literals up to the next special packet code identically: skip them */
+				uint32_t s = uni(sp_find_next(b, nb.pos));
+				if (s == MGL_POS_INF || s > c.n) s = c.n;
+				if (s > nb.pos) {
+					const uint32_t lits = s - nb.pos;
+					const uint32_t cs = lit_steps(nb.ctx_state, lits);
+					nb.pos = bs.pos = s; nb.ctx_state = bs.ctx_state = cs;
+					count = 8;
+					continue;
+				}
+			}
+		}
+		if (nb.pos <= bs.pos && nb.pos < c.n) {
+			/* ---- next neighbour packet: repair rules of packet_slab_neighbour.c:82-117 */
+			const uint32_t p = nb.pos;
+			win_cover(win, c, b.slab, p, lane);
+			mgl_pk pk;
+			if (first_packet) {
+				pk = m_first; /* :169 the mutated packet is coded as is */
+			} else {
+				if (count < 8) count++;
+				const mgl_pk old = (second_set && p == pos + 1) ? m_second : win_pk(win, p);
+				pk = old;
+				uint32_t type = mgl_pk_type(pk);
+				if (type == MGL_SHORT_REP || (type == MGL_LITERAL && count < 4)) {
+					const bool same = nb.dists[0] < p && win_byte(win, p) == c.data[p - nb.dists[0] - 1];
+					if (same) { if (count < 4) pk = MGL_PK_SHORT_REP; }
+					else pk = MGL_PK_LITERAL;
+				}
+				type = mgl_pk_type(pk);
+				if (type == MGL_LONG_REP) {
+					const uint32_t len = mgl_pk_len(pk);
+					uint32_t idx = mgl_pk_dist(pk);
+					walk_from_state(tw, nb);
+					bool ok = long_rep_ok(c, tw, idx, len, lane);
+					for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, tw, idx, len, lane); }
+					pk = mgl_pack(MGL_LONG_REP, idx, len);
+					if (!ok) {
+						const bool best = (nbr_draw(rng) % 4u) == 0;
+						/* the model at p needs every base packet that starts before p priced in */
+						while (bs.pos < p && !ch.overflow) {
+							win_cover(win, c, b.slab, bs.pos, lane);
+							const mgl_pk bpk = win_pk(win, bs.pos);
+							mgl_plan bpl;
+							plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);
+							changes_add<false>(ch, bpl, bs.pos, lane);
+							mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
+						}
+						if (ch.overflow) break;
+						model_at(c, b, ch, probs, T, p, lane, &too_many);
+						if (too_many) break;
+						walk_from_state(tw, nb);
+						walk_window(tw, c, b.slab, lane);
+						mgl_pk picked;
+						if (pick_from_top_k(c, tw, probs, T, lencost, pk, best, rng, lane, &picked)) pk = picked;
+						win_cover(win, c, b.slab, p, lane);
+					}
+				}
+				if (pk != old) {
+					const mgl_pk base_old = (second_set && p == pos + 1) ? uni64(b.slab[p]) : old;
+					journal_set(jn, p, base_old, pk, lane);
+				}
+			}
+			first_packet = false;
+			walked++;
+			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
+			mgl_plan npl;
+			plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+			bool cancelled = false;
+			if (bs.pos == p) {
+				/* the base packet at the same position: identical coding cancels */
+				const mgl_pk bpk = win_pk(win, p);
+				const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
+				mgl_plan bpl;
+				plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
+				cancelled = bpk == pk && nb.ctx_state == bs.ctx_state &&
+				            (ntype != MGL_LITERAL || nb.ctx_state < 7 || npl.match_byte == bpl.match_byte);
+				if (!cancelled) changes_add<false>(ch, bpl, p, lane);
+				mgl_advance(&bs, btype, bdist, blen);
+			}
+			if (!cancelled) changes_add<true>(ch, npl, p, lane);
+			mgl_advance(&nb, ntype, ndist, nlen);
+		} else {
+			/* ---- a base packet the neighbour has already passed over: its events go away */
+			win_cover(win, c, b.slab, bs.pos, lane);
+			const mgl_pk bpk = win_pk(win, bs.pos);
+			mgl_plan bpl;
+			plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);
+			changes_add<false>(ch, bpl, bs.pos, lane);
+			mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
+		}
+	}
+
+	int64_t delta = 0;
+	if (!ch.overflow && !jn.overflow && !too_many) delta = chain_sim(b, ch, T, MGL_POS_INF, nullptr, lane, &too_many);
+	if (jn.overflow) { /* same rule as the full-walk path and the oracle: dropped */
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; }
+		return;
+	}
+	if (ch.overflow || too_many) {
+		/* does not fit the LDS change lists: hand it to the full-walk kernel */
+		if (lane == 0) {
+			const uint32_t slot = atomicAdd(todo_count, 1u);
+			todo[slot] = j;
+			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
+		}
+		return;
+	}
+	const uint64_t total = (uint64_t)((int64_t)ctl->rebuild_cost + delta + ch.direct); /* rebuild_cost: exact cost of the base */
+	uint32_t nd = 0;
+	for (uint32_t i = 0; i < jn.count; i++) {
+		if (jn.old[i] == jn.neu[i]) continue;
+		if (lane == 0) {
+			out.dpos[(size_t)j * MGL_MAX_DIFFS + nd] = jn.pos[i];
+			out.dold[(size_t)j * MGL_MAX_DIFFS + nd] = jn.old[i];
+			out.dnew[(size_t)j * MGL_MAX_DIFFS + nd] = jn.neu[i];
+		}
+		nd++;
+	}
+	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; }
+}

@@ -91,6 +91,11 @@ typedef struct {
 	uint64_t cache_size;
 	uint8_t* out;
 	size_t out_cap, out_len;
+	/* optional event trace (orc_trace_events): one record per coded bit */
+	const uint16_t* tr_base;
+	uint32_t* tr_ctx; uint8_t* tr_bit; uint16_t* tr_prob; uint32_t* tr_pos;
+	size_t tr_cap, tr_len;
+	uint32_t tr_cur_pos;
 } orc_sink;
 
 static void rc_put(orc_sink* s, uint8_t b)
@@ -119,6 +124,15 @@ static void rc_shift_low(orc_sink* s)
 static inline void put_bit(orc_sink* s, uint16_t* prob, unsigned bit)
 {
 	unsigned v = *prob;
+	if (s->tr_base) {
+		if (s->tr_len < s->tr_cap) {
+			s->tr_ctx[s->tr_len] = (uint32_t)(prob - s->tr_base);
+			s->tr_bit[s->tr_len] = (uint8_t)bit;
+			s->tr_prob[s->tr_len] = (uint16_t)v;
+			s->tr_pos[s->tr_len] = s->tr_cur_pos;
+		}
+		s->tr_len++;
+	}
 	if (s->kind == 0) {
 		s->perp += g_cost[bit ? 2048 - v : v];
 	} else {
@@ -346,6 +360,34 @@ uint64_t orc_cost_slab(orc_ctx* c, const orc_packet* slab, uint64_t* cum, size_t
 	if (dists_out) memcpy(dists_out, st.dists, sizeof st.dists);
 	free(probs);
 	return s.perp;
+}
+
+/* Every coded bit of a slab walk, in coding order: probability index (reference struct order),
+ * bit, probability before the update, position of the packet that coded it; plus the walk
+ * state before every packet (pk_state: ctx_state, dists[4] per walked packet).  Used to
+ * check the device's per-context event chains and state records. */
+size_t orc_trace_events(orc_ctx* c, const orc_packet* slab, uint32_t* ev_ctx, uint8_t* ev_bit, uint16_t* ev_prob,
+                        uint32_t* ev_pos, size_t cap, uint32_t* pk_pos, uint32_t* pk_state, size_t pk_cap, size_t* npk)
+{
+	uint16_t* probs = (uint16_t*)malloc(sizeof(uint16_t) * c->L.total);
+	orc_state st;
+	state_init(c, &st, probs);
+	orc_sink s = { 0 };
+	s.tr_base = probs; s.tr_ctx = ev_ctx; s.tr_bit = ev_bit; s.tr_prob = ev_prob; s.tr_pos = ev_pos; s.tr_cap = cap;
+	size_t k = 0;
+	while (st.pos < c->n) {
+		if (k < pk_cap) {
+			pk_pos[k] = (uint32_t)st.pos;
+			pk_state[5 * k] = st.ctx_state;
+			for (int i = 0; i < 4; i++) pk_state[5 * k + 1 + i] = st.dists[i];
+		}
+		k++;
+		s.tr_cur_pos = (uint32_t)st.pos;
+		encode_packet(c, &st, &s, slab[st.pos]);
+	}
+	if (npk) *npk = k;
+	free(probs);
+	return s.tr_len;
 }
 
 /* ---------------------------------------------------------------- enumeration */

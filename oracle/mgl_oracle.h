@@ -55,6 +55,11 @@ const uint16_t* orc_cost_table(void);
 uint64_t orc_cost_slab(orc_ctx* c, const orc_packet* slab, uint64_t* cum, size_t* npackets,
                        uint16_t* probs_out, uint8_t* ctx_state_out, uint32_t* dists_out);
 
+/* every coded bit of the walk (context index in reference struct order, bit, probability
+ * before the update, position of its packet) + the walk state before each packet */
+size_t orc_trace_events(orc_ctx* c, const orc_packet* slab, uint32_t* ev_ctx, uint8_t* ev_bit, uint16_t* ev_prob,
+                        uint32_t* ev_pos, size_t cap, uint32_t* pk_pos, uint32_t* pk_state, size_t pk_cap, size_t* npk);
+
 /* bigram match index query, substring_enumerator.c:85-105 */
 size_t orc_substrings(orc_ctx* c, size_t pos, size_t max_len, uint32_t* offs, uint32_t* lens, size_t cap);
 

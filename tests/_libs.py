@@ -139,6 +139,25 @@ class Oracle:
             r["probs"] = probs
         return r
 
+    def trace_events(self, slab):
+        """(ctx, bit, prob_before, pos) per coded bit in coding order + (pos, ctx_state, dists) per packet."""
+        cap = 9 * self.n + 64
+        ctx = np.zeros(cap, dtype=np.uint32)
+        bit = np.zeros(cap, dtype=np.uint8)
+        prob = np.zeros(cap, dtype=np.uint16)
+        pos = np.zeros(cap, dtype=np.uint32)
+        pk_pos = np.zeros(self.n, dtype=np.uint32)
+        pk_state = np.zeros(5 * self.n, dtype=np.uint32)
+        npk = C.c_size_t(0)
+        fn = self.L.orc_trace_events
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        ne = fn(self.h, ptr(slab), ptr(ctx), ptr(bit), ptr(prob), ptr(pos), cap, ptr(pk_pos), ptr(pk_state), self.n,
+                C.addressof(npk))
+        assert ne <= cap
+        return dict(ctx=ctx[:ne], bit=bit[:ne], prob=prob[:ne], pos=pos[:ne], pk_pos=pk_pos[: npk.value],
+                    pk_state=pk_state[: 5 * npk.value].reshape(-1, 5))
+
     def substrings(self, pos, max_len=273, cap=1 << 20):
         offs = np.zeros(cap, dtype=np.uint32)
         lens = np.zeros(cap, dtype=np.uint32)

@@ -1,0 +1,128 @@
+"""The incremental engine's base structures (bitmaps, special-state records, dense
+checkpoints, per-context event chains) against the CPU oracle's event trace, and the two
+device engines against each other.  `-m gpu`."""
+import numpy as np
+import pytest
+
+from _libs import Oracle, literal_slab, walk
+from conftest import slab_from_rle
+from megalania_amd import binding, corpus
+
+pytestmark = pytest.mark.gpu
+
+INF = 0xFFFFFFFF
+
+
+def ref_to_product_ctx(r, lit):
+    """reference struct order (lit|len|rep_len|dist|cs) -> product order (cs|len|rep_len|dist|lit)"""
+    r = np.asarray(r, dtype=np.int64)
+    out = np.empty_like(r)
+    a = r < lit
+    out[a] = 1847 + r[a]
+    b = (r >= lit) & (r < lit + 514)
+    out[b] = 432 + (r[b] - lit)
+    c = (r >= lit + 514) & (r < lit + 1028)
+    out[c] = 946 + (r[c] - lit - 514)
+    d = (r >= lit + 1028) & (r < lit + 1415)
+    out[d] = 1460 + (r[d] - lit - 1028)
+    e = r >= lit + 1415
+    out[e] = r[e] - lit - 1415
+    return out
+
+
+def check_base(sa, o, slab, data):
+    n = len(data)
+    tr = o.trace_events(slab)
+    total = sa.nprobs
+    ctx = ref_to_product_ctx(tr["ctx"], 0x300)
+    off = sa.debug_dump(0, np.uint32)
+    ln = sa.debug_dump(1, np.uint32)
+    cap = sa.debug_dump(8, np.uint32)
+    cpos = sa.debug_dump(2, np.uint32)
+    cev = sa.debug_dump(3, np.uint16)
+    ev = (tr["bit"].astype(np.uint16) << 15) | tr["prob"]
+    fin = o.cost_slab(slab, want_probs=True)["probs"]
+    fin_prod = np.empty(total, dtype=np.uint16)
+    fin_prod[ref_to_product_ctx(np.arange(total), 0x300)] = fin
+    assert int(ln.sum()) == len(ctx)
+    order = np.argsort(ctx, kind="stable")
+    sctx, spos, sev = ctx[order], tr["pos"][order], ev[order]
+    starts = np.searchsorted(sctx, np.arange(total))
+    for c in range(total):
+        k, m = int(off[c]), int(ln[c])
+        assert m + 1 <= cap[c]
+        s = starts[c]
+        assert (cpos[k:k + m] == spos[s:s + m]).all(), c
+        assert (cev[k:k + m] == sev[s:s + m]).all(), c
+        assert cpos[k + m] == INF and cev[k + m] == fin_prod[c], c
+    # bitmaps
+    w = walk(slab)
+    on = np.zeros(n, dtype=bool)
+    on[w] = True
+    onw = sa.debug_dump(4, np.uint64)
+    got_on = np.unpackbits(onw.view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert (got_on == on).all()
+    special = on & (slab["type"] != 1)
+    sp0 = sa.debug_dump(5, np.uint64)
+    got_sp = np.unpackbits(sp0.view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert (got_sp == special).all()
+    # state records before every special packet
+    st = sa.debug_dump(6, np.uint32).reshape(n, 8)
+    pk_state = dict(zip((int(p) for p in tr["pk_pos"]), tr["pk_state"]))
+    for p in np.nonzero(special)[0]:
+        assert (st[p, :5] == pk_state[int(p)]).all(), p
+    # dense checkpoints: model before the first packet at or after every 64th byte
+    ck = sa.debug_dump(7, np.uint16).reshape(-1, (total + 7) // 8 * 8)
+    probs = np.full(total, 1024, dtype=np.int64)
+    ei, nck = 0, 0
+    for p in w:
+        while nck * 64 <= p:
+            assert (ck[nck, :total] == probs).all(), nck
+            nck += 1
+        while ei < len(ctx) and tr["pos"][ei] == p:
+            c, b = ctx[ei], int(tr["bit"][ei])
+            v = probs[c]
+            probs[c] = v - (v >> 5) if b else v + ((2048 - v) >> 5)
+            ei += 1
+
+
+@pytest.mark.parametrize("name", ["lorem4k", "enwik3k", "reps", "zeros600"])
+def test_base_structures_match_oracle_trace(name, golden, golden_input):
+    data = golden_input(name)
+    n = len(data)
+    sa = binding.SA(data, neighbours_per_step=8)
+    o = Oracle(data)
+    slabs = [literal_slab(n)]
+    if name in golden["evolved_walks"]:
+        slabs.append(slab_from_rle(n, golden["evolved_walks"][name]))
+    for wk in golden["walks"]:
+        if wk["input"] == name and wk["name"].endswith("_reps"):
+            slabs.append(slab_from_rle(n, wk["packets"]))
+    for slab in slabs:
+        sa.set_slab(slab.astype(binding.PACKET))
+        check_base(sa, o, slab, data)
+    sa.close()
+
+
+def test_engines_agree_on_c2_neighbours():
+    """Full-size BASELINE configs[1]: every neighbour of a step costed by the incremental engine
+    equals the full-walk engine (which equals the oracle, test_gpu_parity.py)."""
+    data, _ = corpus.config_input("c2")
+    K, seed = 1024, 4242
+    inc = binding.SA(data, neighbours_per_step=K, seed=seed)
+    full = binding.SA(data, neighbours_per_step=K, seed=seed, fullwalk=True)
+    for rounds in range(3):
+        for step in (rounds * 10, rounds * 10 + 1):
+            ci, ni, di = inc.neighbours(step)
+            cf, nf, df = full.neighbours(step)
+            assert (ci == cf).all(), np.nonzero(ci != cf)[0][:8]
+            assert (ni == nf).all()
+            for j in range(K):
+                assert (di[j][: ni[j]] == df[j][: nf[j]]).all(), j
+        si, sf = inc.run(6), full.run(6)
+        assert si["current_cost"] == sf["current_cost"] and si["evaluations"] == sf["evaluations"]
+    a, ca = inc.current()
+    b, cb = full.current()
+    assert ca == cb and (a == b).all()
+    inc.close()
+    full.close()

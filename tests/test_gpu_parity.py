@@ -109,14 +109,18 @@ def _check_neighbours(sa, o, slab, seed, step, K):
     return costs
 
 
+ENGINES = pytest.mark.parametrize("fullwalk", [False, True], ids=["incremental", "fullwalk"])
+
+
+@ENGINES
 @pytest.mark.parametrize("name", ["lorem4k", "enwik3k", "reps", "zeros600", "rand2k"])
-def test_neighbours_bit_exact_vs_oracle(name, golden, golden_input):
+def test_neighbours_bit_exact_vs_oracle(name, fullwalk, golden, golden_input):
     """Every neighbour of a step: device cost and journal == oracle (same counter RNG, same
     canonical top-K, same mutate/repair rules), from an all-literal and from an evolved base."""
     data = golden_input(name)
     n = len(data)
     K, seed = 128, 99
-    sa = sa_for(name + "_nb", data, neighbours_per_step=K, seed=seed)
+    sa = sa_for(name + "_nb", data, neighbours_per_step=K, seed=seed, fullwalk=fullwalk)
     o = Oracle(data, dict_limit=0x400000)
     bases = [literal_slab(n)]
     if name in golden["evolved_walks"]:
@@ -130,14 +134,15 @@ def test_neighbours_bit_exact_vs_oracle(name, golden, golden_input):
             _check_neighbours(sa, o, base, seed, step, K)
 
 
-def test_sa_run_trajectory_vs_oracle():
+@ENGINES
+def test_sa_run_trajectory_vs_oracle(fullwalk):
     """mgl_sa_run step by step against orc_sa_batched: same winner, same accept decision,
     same current/best cost every step, same final slabs; the stream decodes."""
     data = corpus.lorem(1800)
     n = len(data)
     K, seed, steps = 48, 1673551, 60
     ipe = steps  # iterations per epoch: the oracle helper derives i = gstep % ipe
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed, iters_per_epoch=ipe)
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed, iters_per_epoch=ipe, fullwalk=fullwalk)
     o = Oracle(data, dict_limit=0x400000)
     slab, best = literal_slab(n), literal_slab(n)
     ref = o.sa_batched(slab, best, 0, 0, seed, K, 0, ipe, 0, steps)
@@ -165,12 +170,13 @@ def test_sa_run_trajectory_vs_oracle():
     sa.close()
 
 
+@ENGINES
 @pytest.mark.parametrize("data", [b"x", b"ab", b"aaaa", rand_bytes(70, 5)], ids=["n1", "n2", "aaaa", "rand70"])
-def test_tiny_and_incompressible_inputs(data):
+def test_tiny_and_incompressible_inputs(data, fullwalk):
     """Edge cases: inputs where few or no neighbours exist (the reference spins forever at
     main.c:81-84 there); failed generates come back as UINT64_MAX and nothing crashes."""
     K, seed = 16, 5
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed)
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed, fullwalk=fullwalk)
     o = Oracle(data, dict_limit=0x400000)
     base = literal_slab(len(data))
     assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]

@@ -76,6 +76,8 @@ typedef struct {
                              slow engine) instead of incrementally against the base chains;
                              both engines return identical numbers */
 
+#define MGL_F_PROFILE 4u  /* diagnostic: per-phase cycle counters in the neighbour kernel */
+
 typedef struct {
 	uint64_t steps;          /* SA steps executed by this call */
 	uint64_t evaluations;    /* neighbour evaluations that produced a cost (successful generates) */

@@ -17,8 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "_build")
 
-HIP_SRC = [os.path.join(HERE, "csrc", f) for f in ("mgl_api.hip", "mgl_kernels.hip", "mgl_device.h", "mgl_model.h",
-                                                   "mgl_cost_table.inc")]
+HIP_SRC = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))]
 HIP_SRC.append(os.path.join(ROOT, "include", "megalania_hip.h"))
 HOST_SRC = [os.path.join(HERE, "host", f) for f in ("mgl_host.c", "mgl_host.h")]
 HOST_SRC += [os.path.join(HERE, "csrc", "mgl_model.h"), os.path.join(HERE, "csrc", "mgl_cost_table.inc"),

@@ -76,6 +76,7 @@ struct mgl_sa {
 	/* incremental path (mgl_kernels2.hip) */
 	bool incremental;
 	Base2 b2;
+	unsigned long long* d_prof; /* 16 u64: per-phase cycles + counts, only with MGL_F_PROFILE */
 	uint32_t* d_todo;       /* [0] = count, [1..K] = neighbour indices for the full-walk fallback */
 	uint32_t per_wave2, waves_per_block2, nbr2_lds, build_lds;
 	size_t b2_bytes;
@@ -141,7 +142,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	hipLaunchKernelGGL(k_neighbours2, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx, sa->b2,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1,
-	                   sa->d_todo);
+	                   sa->d_todo, sa->d_prof);
 	/* neighbours that did not fit the LDS change lists: exact full walk from byte 0 */
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
@@ -180,7 +181,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	dfree(sa->b2.sp0); dfree(sa->b2.sp1); dfree(sa->b2.sp2); dfree(sa->b2.sp_state); dfree(sa->b2.ck_probs);
 	dfree(sa->b2.ch_off); dfree(sa->b2.ch_len); dfree(sa->b2.ch_cap); dfree(sa->b2.ch_pos); dfree(sa->b2.ch_ev);
-	dfree(sa->b2.pool_top); dfree(sa->d_todo);
+	dfree(sa->b2.pool_top); dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
 	for (hipEvent_t e : sa->ev_pool) (void)hipEventDestroy(e);
 	if (sa->ev_begin) (void)hipEventDestroy(sa->ev_begin);
@@ -283,6 +284,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * (size_t)b.pool_cap)); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
 		HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * (size_t)b.pool_cap)); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
 		HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
+		if (sa->cfg.flags & MGL_F_PROFILE) {
+			HIPCHK(hipMalloc(&sa->d_prof, sizeof(unsigned long long) * 24));
+			HIPCHK(hipMemset(sa->d_prof, 0, sizeof(unsigned long long) * 24));
+		}
 		HIPCHK(hipMalloc(&sa->d_todo, sizeof(uint32_t) * (K + 1)));
 		HIPCHK(hipMemset(sa->d_todo, 0, sizeof(uint32_t) * (K + 1)));
 		sa->b2_bytes = bytes;
@@ -641,6 +646,8 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 6: src = b.sp_state; sz = sizeof(uint32_t) * 8 * (size_t)sa->n; break;
 	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
+	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * 24 : 0; break;
+	case 10: src = sa->d_todo; sz = sizeof(uint32_t); break;
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
 	}
 	*bytes = sz;

@@ -110,12 +110,12 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 		const unsigned long long m = __ballot(nz);
 		if (lane == 0) b.sp2[v] = m;
 	}
-	/* chain offsets: capacity = len + len/2 + 32 (+1 sentinel); lanes own contiguous context ranges */
+	/* chain offsets: capacity = len + len/2 + 33 rounded up to 8 (incl. the sentinel); lanes own contiguous context ranges */
 	{
 		const uint32_t per = (total + 63u) / 64u;
 		const uint32_t lo = lane * per, hi = (lo + per) < total ? (lo + per) : total;
 		uint32_t sum = 0;
-		for (uint32_t i = lo; i < hi; i++) sum += cnt[i] + (cnt[i] >> 1) + 33u;
+		for (uint32_t i = lo; i < hi; i++) sum += (cnt[i] + (cnt[i] >> 1) + 33u + 7u) & ~7u;
 		uint32_t incl = sum;
 		for (int o = 1; o < 64; o <<= 1) {
 			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 		}
 		uint32_t run = incl - sum;
 		for (uint32_t i = lo; i < hi; i++) {
-			const uint32_t cap = cnt[i] + (cnt[i] >> 1) + 33u;
+			const uint32_t cap = (cnt[i] + (cnt[i] >> 1) + 33u + 7u) & ~7u; /* multiple of 8: 16-byte aligned chains */
 			off[i] = run;
 			b.ch_off[i] = run; b.ch_len[i] = cnt[i]; b.ch_cap[i] = cap;
 			run += cap;
@@ -209,6 +209,7 @@ struct Changes {
 	uint16_t* uctx;
 	uint32_t n_ins, n_rem; /* uniform */
 	int64_t direct;        /* (inserted - removed) direct-bit cost, uniform */
+	unsigned long long* dbg; /* diagnostic counters (MGL_F_PROFILE), else nullptr */
 	bool overflow;
 };
 
@@ -275,14 +276,21 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 		const uint32_t x0 = ipos0 < rpos0 ? ipos0 : rpos0;
 		const uint32_t* cpos = b.ch_pos + b.ch_off[cx];
 		const uint16_t* cev = b.ch_ev + b.ch_off[cx];
-		uint32_t k = chain_lower_bound(cpos, b.ch_len[cx], x0);
+		const uint32_t clen = b.ch_len[cx];
+		uint32_t k = chain_lower_bound(cpos, clen, x0);
 		uint32_t p = cev[k] & 0x7FFu;
-		bool at_limit = false;
+		bool at_limit = false, ended = false;
+		uint32_t iters = 0;
+		/* ---- part 1: while this context still has changes ahead (or a limit applies):
+		 * merge base entries and inserted events by position */
 		for (;;) {
+			const bool pending = ii < ch.n_ins || ri < ch.n_rem;
+			if (!pending && limit == MGL_POS_INF) break; /* -> part 2 */
+			iters++;
 			const uint32_t bpos = cpos[k];
 			const uint32_t ipos = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
 			if (ipos < bpos) {
-				if (ipos >= limit) { at_limit = true; break; }
+				if (ipos >= limit) { at_limit = true; ended = true; break; }
 				const uint32_t bit = ch.ins_key[ii] >> 15;
 				delta += T[bit ? 2048u - p : p];
 				p = mgl_prob_update(p, bit);
@@ -290,12 +298,23 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 				while (ii < ch.n_ins && (ch.ins_key[ii] & 0x7FFFu) != cx) ii++;
 				continue;
 			}
-			if (bpos == MGL_POS_INF) break;         /* chain exhausted */
-			if (bpos >= limit) { at_limit = true; break; }
+			if (bpos == MGL_POS_INF) { ended = true; break; }          /* chain exhausted */
+			if (bpos >= limit) { at_limit = true; ended = true; break; }
 			const uint32_t ev = cev[k];
 			const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
-			const bool pending = ii < ch.n_ins || ri < ch.n_rem;
-			if (!pending && p == bp) break;          /* re-coupled: identical from here on */
+			if (p == bp) {
+				if (!pending) { ended = true; break; }   /* re-coupled, nothing ahead (limit mode) */
+				/* re-coupled, but this context changes again further on: everything up to
+				 * that position is coded exactly as in the base, so jump there */
+				const uint32_t rpos = ri < ch.n_rem ? ch.rem_pos[ri] : MGL_POS_INF;
+				const uint32_t nxt = ipos < rpos ? ipos : rpos;
+				if (nxt > bpos) {
+					if (nxt >= limit) { ended = true; break; } /* the base value holds at the limit */
+					k += chain_lower_bound(cpos + k, clen - k, nxt);
+					p = cev[k] & 0x7FFu;
+					continue;
+				}
+			}
 			delta -= T[bb ? 2048u - bp : bp];
 			if (ri < ch.n_rem && ch.rem_pos[ri] == bpos) {
 				ri++;
@@ -306,7 +325,29 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 			}
 			k++;
 		}
-		if (overlay && (at_limit || cpos[k] == MGL_POS_INF)) overlay[cx] = (uint16_t)p;
+		/* ---- part 2: no change ahead: follow the base chain until the probability re-joins
+		 * the base trajectory.  Only (bit, base probability) is needed: 8 entries per 16-byte
+		 * load, so a cache line is fetched once, not once per entry. */
+		while (!ended) {
+			const uint32_t start = k & 7u, k8 = k - start;
+			const uint4 q = *reinterpret_cast<const uint4*>(cev + k8); /* chains start 16-byte aligned */
+			const uint32_t w0 = q.x, w1 = q.y, w2 = q.z, w3 = q.w;
+#pragma unroll
+			for (uint32_t e = 0; e < 8; e++) {
+				if (ended || e < start) continue;
+				if (k8 + e >= clen) { ended = true; continue; }            /* chain exhausted */
+				const uint32_t wd = e < 2 ? w0 : e < 4 ? w1 : e < 6 ? w2 : w3;
+				const uint32_t ev = (wd >> ((e & 1u) * 16u)) & 0xFFFFu;
+				const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+				if (p == bp) { ended = true; continue; }                   /* re-coupled */
+				delta += (int64_t)T[bb ? 2048u - p : p] - (int64_t)T[bb ? 2048u - bp : bp];
+				p = mgl_prob_update(p, bb);
+				iters++;
+			}
+			k = k8 + 8;
+		}
+		if (ch.dbg) atomicMax(&ch.dbg[21], (unsigned long long)iters);
+		if (overlay && (at_limit || (limit != MGL_POS_INF && cpos[k] == MGL_POS_INF))) overlay[cx] = (uint16_t)p;
 	}
 	/* signed wave sum */
 	uint64_t u = (uint64_t)delta;
@@ -316,6 +357,20 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 }
 
 /* ================================================================== k_neighbours2 */
+
+/* optional per-phase cycle accounting (diagnostic: prof == nullptr in normal runs) */
+struct Prof {
+	unsigned long long* acc;
+	unsigned long long t;
+};
+__device__ __forceinline__ void prof_start(Prof& p, unsigned long long* acc) { p.acc = acc; if (acc) p.t = __builtin_readcyclecounter(); }
+__device__ __forceinline__ void prof_mark(Prof& p, int phase, uint32_t lane)
+{
+	if (!p.acc) return;
+	const unsigned long long now = __builtin_readcyclecounter();
+	if (lane == 0) { atomicAdd(&p.acc[phase], now - p.t); atomicAdd(&p.acc[8 + phase], 1ull); atomicMax(&p.acc[16 + phase], now - p.t); }
+	p.t = __builtin_readcyclecounter();
+}
 
 struct Win {
 	uint32_t base;
@@ -384,7 +439,7 @@ __device__ __forceinline__ void walk_from_state(Walk& w, const mgl_wstate& st)
 
 __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
-                                                     uint32_t* todo, uint32_t* todo_count)
+                                                     uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
@@ -432,6 +487,9 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Co
 			target = uni(bits ? (wd << 6) + ctz64(bits) : 0u);
 		}
 	}
+	Prof prof;
+	prof_start(prof, prof_acc);
+	ch.dbg = prof_acc;
 	const uint32_t pos = target;
 	mgl_wstate nb = uni_state(base_state_at(b, pos)); /* neighbour's walk state */
 	mgl_wstate bs = nb;                               /* base's walk state */
@@ -443,6 +501,7 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Co
 	const mgl_pk first = win_pk(win, pos);
 	mgl_pk m_first = first, m_second = 0;
 	bool second_set = false, mutated = false;
+	prof_mark(prof, 0, lane); /* state at target */
 	if (pos + 1 < c.n && (nbr_draw(rng) % 2u) == 0) {
 		const mgl_pk second = uni64(b.slab[pos + 1]);
 		const uint32_t ft = mgl_pk_type(first), flen = mgl_pk_len(first);
@@ -464,6 +523,7 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Co
 	}
 	if (!mutated) {
 		model_at(c, b, ch, probs, T, pos, lane, &too_many);
+		prof_mark(prof, 1, lane); /* model at target */
 		walk_from_state(tw, nb);
 		walk_window(tw, c, b.slab, lane);
 		mgl_pk picked;
@@ -473,6 +533,7 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Co
 		}
 		m_first = picked;
 		journal_set(jn, pos, first, m_first, lane);
+		prof_mark(prof, 2, lane); /* top-K */
 	}
 
 	/* ---- two-pointer walk over neighbour packets (nb) and base packets (bs) */
@@ -581,8 +642,10 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Co
 		}
 	}
 
+	prof_mark(prof, 3, lane); /* window walk */
 	int64_t delta = 0;
 	if (!ch.overflow && !jn.overflow && !too_many) delta = chain_sim(b, ch, T, MGL_POS_INF, nullptr, lane, &too_many);
+	prof_mark(prof, 4, lane); /* chain re-simulation */
 	if (jn.overflow) { /* same rule as the full-walk path and the oracle: dropped */
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; }
 		return;

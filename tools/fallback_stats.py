@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Diagnostic: how many neighbours per step fall back to the full-walk kernel."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from megalania_amd import binding, corpus
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+data, desc = corpus.config_input(cfg)
+sa = binding.SA(data, neighbours_per_step=4096, timing=True)
+fb = []
+for s in range(steps):
+    st = sa.run(1)
+    fb.append((int(sa.debug_dump(10, np.uint32)[0]), round(st["gpu_ms_neighbours"], 2), st["packets"], st["failed"]))
+print(fb)

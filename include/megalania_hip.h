@@ -92,6 +92,8 @@ typedef struct {
 	double gpu_ms_neighbours;/* sum over launches of the neighbour kernel (MGL_F_TIMING) */
 	double gpu_ms_rebuild;   /* sum over launches of the base rebuild kernel (MGL_F_TIMING) */
 	uint64_t neighbour_launches;
+	uint64_t full_rebuilds;       /* accepted steps whose base update fell back to a full rebuild */
+	uint64_t fallback_neighbours; /* neighbours costed by the full-walk kernel instead of incrementally */
 } mgl_sa_stats;
 
 typedef struct {

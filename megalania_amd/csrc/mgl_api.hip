@@ -4,6 +4,7 @@
  */
 #include "mgl_kernels.hip"
 #include "mgl_kernels2.hip"
+#include "mgl_kernels3.hip"
 #include "../../include/megalania_hip.h"
 
 #include <math.h>
@@ -80,6 +81,9 @@ struct mgl_sa {
 	uint32_t* d_todo;       /* [0] = count, [1..K] = neighbour indices for the full-walk fallback */
 	uint32_t per_wave2, waves_per_block2, nbr2_lds, build_lds;
 	size_t b2_bytes;
+	ApplyBuf ab;
+	uint32_t apply_blocks;
+	bool incremental_apply;
 	hipEvent_t ev_begin, ev_end;
 	std::vector<hipEvent_t> ev_pool;
 };
@@ -127,6 +131,18 @@ static int rebuild_base(mgl_sa* sa, int after_accept)
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
+/* incremental engine, after k_decide: fold the winner into the base structures */
+static int launch_apply(mgl_sa* sa)
+{
+	hipLaunchKernelGGL(k_apply_walk, dim3(1), dim3(64), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, sa->ab);
+	hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
+	                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(256), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
+	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
+	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
 static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
@@ -141,7 +157,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 	HIPCHK(hipMemsetAsync(sa->d_todo, 0, sizeof(uint32_t), sa->stream));
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	hipLaunchKernelGGL(k_neighbours2, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx, sa->b2,
-	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1,
+	                   sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1,
 	                   sa->d_todo, sa->d_prof);
 	/* neighbours that did not fit the LDS change lists: exact full walk from byte 0 */
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
@@ -182,6 +198,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->b2.sp0); dfree(sa->b2.sp1); dfree(sa->b2.sp2); dfree(sa->b2.sp_state); dfree(sa->b2.ck_probs);
 	dfree(sa->b2.ch_off); dfree(sa->b2.ch_len); dfree(sa->b2.ch_cap); dfree(sa->b2.ch_pos); dfree(sa->b2.ch_ev);
 	dfree(sa->b2.pool_top); dfree(sa->d_todo); dfree(sa->d_prof);
+	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
+	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
 	for (hipEvent_t e : sa->ev_pool) (void)hipEventDestroy(e);
 	if (sa->ev_begin) (void)hipEventDestroy(sa->ev_begin);
@@ -291,6 +309,22 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&sa->d_todo, sizeof(uint32_t) * (K + 1)));
 		HIPCHK(hipMemset(sa->d_todo, 0, sizeof(uint32_t) * (K + 1)));
 		sa->b2_bytes = bytes;
+		sa->incremental_apply = getenv("MGL_NO_INCREMENTAL_APPLY") == nullptr;
+		{
+			ApplyBuf& ab = sa->ab;
+			memset(&ab, 0, sizeof ab);
+			sa->apply_blocks = 32;
+			ab.scratch_stride = (uint32_t)n + 64u;
+			HIPCHK(hipMalloc(&ab.hdr, sizeof(uint32_t) * 16));
+			HIPCHK(hipMemset(ab.hdr, 0, sizeof(uint32_t) * 16));
+			HIPCHK(hipMalloc(&ab.ins_key, sizeof(uint16_t) * MGL_APPLY_CAP));
+			HIPCHK(hipMalloc(&ab.rem_key, sizeof(uint16_t) * MGL_APPLY_CAP));
+			HIPCHK(hipMalloc(&ab.ins_pos, sizeof(uint32_t) * MGL_APPLY_CAP));
+			HIPCHK(hipMalloc(&ab.rem_pos, sizeof(uint32_t) * MGL_APPLY_CAP));
+			HIPCHK(hipMalloc(&ab.tctx, sizeof(uint16_t) * 16384));
+			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
+			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
+		}
 		sa->per_wave2 = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) + MGL_UCTX_CAP * 2u;
 		sa->waves_per_block2 = 4;
 		while (sa->waves_per_block2 > 1 && 4096u + sa->waves_per_block2 * sa->per_wave2 > 160u * 1024u) sa->waves_per_block2--;
@@ -412,13 +446,19 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
 		if ((rc = launch_neighbours(sa, ~0ull))) return rc;
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
+		const bool inc_apply = sa->incremental && sa->incremental_apply;
 		hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
-		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh);
-		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
-		                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh, inc_apply ? 0 : 1);
 		HIPCHK(hipGetLastError());
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
-		if ((rc = rebuild_base(sa, 1))) return rc;
+		if (inc_apply) {
+			if ((rc = launch_apply(sa))) return rc;
+		} else {
+			hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
+			                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+			HIPCHK(hipGetLastError());
+			if ((rc = rebuild_base(sa, 1))) return rc;
+		}
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 	}
 	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
@@ -445,6 +485,8 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			stats->gpu_ms_rebuild += ms;
 		}
 		stats->neighbour_launches = timed_steps;
+		stats->full_rebuilds = after.full_rebuilds - before.full_rebuilds;
+		stats->fallback_neighbours = after.fallback_nbrs - before.fallback_nbrs;
 	}
 	if (after.error_flags) {
 		char buf[96];

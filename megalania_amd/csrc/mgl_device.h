@@ -58,6 +58,9 @@ struct Control {
 	uint64_t packets, rebuild_cost;
 	uint32_t phase;
 	uint32_t accepted_flag, copy_best_flag, dirty_pos, winner;
+	uint32_t apply_failed; /* the incremental accept did not fit: rebuild from the slab */
+	uint32_t full_rebuilds;  /* accepts that went through k_build */
+	uint64_t fallback_nbrs;  /* neighbours costed by the full-walk kernel (did not fit the LDS lists) */
 	uint32_t final_ctx_state;
 	uint32_t final_dists[4];
 	uint32_t error_flags;

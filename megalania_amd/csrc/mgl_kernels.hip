@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 /* Best-of-K + the accept rule of main.c:86-96, then the winner's
  * journal is applied to the base slab.  One block. */
 __global__ void __launch_bounds__(256) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, uint32_t K, uint64_t seed,
-                                                uint64_t iters_per_epoch, uint64_t sqrt_thresh)
+                                                uint64_t iters_per_epoch, uint64_t sqrt_thresh, int apply_journal)
 {
 	__shared__ uint64_t s_key[256];
 	__shared__ uint64_t s_cnt[256 * 2];
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(256) k_decide(DevCtx c, BaseView b, Control* c
 	}
 	__syncthreads();
 	const uint32_t winner = s_winner;
-	if (winner == ~0u) return;
+	if (winner == ~0u || !apply_journal) return; /* incremental engine: k_apply_walk writes the journal */
 	const uint32_t nd = out.ndiffs[winner];
 	if (tid < nd) b.slab[out.dpos[(size_t)winner * MGL_MAX_DIFFS + tid]] = out.dnew[(size_t)winner * MGL_MAX_DIFFS + tid];
 }

@@ -40,7 +40,10 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 	uint32_t* off = cnt + b.ck_elems;
 	const uint32_t lane = threadIdx.x;
 	const uint32_t total = c.L.total;
-	if (check_cost && !ctl->accepted_flag) return; /* per-step rebuild: nothing moved */
+	/* check_cost: 0 = unconditional build; 1 = per-step rebuild after an accept;
+	 * 2 = only when the incremental accept (k_apply_*) gave up */
+	if (check_cost && !ctl->accepted_flag) return;
+	if (check_cost == 2 && !ctl->apply_failed) return;
 	for (uint32_t i = lane; i < 2048; i += 64) T[i] = c.cost_tbl[i];
 	for (uint32_t i = lane; i < b.ck_elems; i += 64) { cnt[i] = 0; off[i] = 0; }
 	wave_sync();
@@ -179,6 +182,14 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 		w.packets++;
 	}
 	wave_sync();
+	/* checkpoints whose boundary lies behind the last packet start hold the final model, so
+	 * that every checkpoint is defined (k_apply_chains relies on that) */
+	while (next_ck < b.nck) {
+		uint32_t* dst = (uint32_t*)(b.ck_probs + (size_t)next_ck * b.ck_elems);
+		const uint32_t* src = (const uint32_t*)probs;
+		for (uint32_t i = lane; i < b.ck_elems / 2; i += 64) dst[i] = src[i];
+		next_ck++;
+	}
 	/* sentinels: position = infinity, probability = the context's final value */
 	for (uint32_t i = lane; i < total; i += 64) {
 		const uint32_t k = off[i] + cnt[i];
@@ -195,6 +206,7 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 		if (check_cost) {
 			if (ctl->cur_cost != cost) atomicOr(&ctl->error_flags, MGL_ERR_REBUILD_MISMATCH);
 			ctl->accepted_flag = 0;
+			ctl->full_rebuilds++;
 		}
 	}
 }
@@ -437,7 +449,7 @@ __device__ __forceinline__ void walk_from_state(Walk& w, const mgl_wstate& st)
 	w.st = st;
 }
 
-__global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Control* ctl, uint64_t seed,
+__global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc)
 {
@@ -655,6 +667,7 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, const Co
 		if (lane == 0) {
 			const uint32_t slot = atomicAdd(todo_count, 1u);
 			todo[slot] = j;
+			atomicAdd((unsigned long long*)&ctl->fallback_nbrs, 1ull);
 			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
 		}
 		return;

@@ -1,0 +1,413 @@
+/*
+ * mgl_kernels3.hip -- accepting a neighbour without rebuilding the base.
+ *
+ *   k_apply_walk    one wavefront re-runs the two-pointer walk of the winning neighbour (its
+ *                   packets are known from the journal: no RNG, no top-K) against the old base:
+ *                   updates the on-walk / special bitmaps and the state records of every special
+ *                   packet it passes, collects the inserted / removed events, lists the touched
+ *                   probability contexts, then writes the journal into the slab.
+ *   k_apply_chains  one workgroup per touched context: re-simulates the context from its first
+ *                   change, splices the new entries into its chain (the tail moves by the net
+ *                   insert/remove count), and patches that context's value in every dense
+ *                   checkpoint between the change and the point where it re-joins the old
+ *                   trajectory.
+ * Anything that does not fit (event lists, span buffers, chain capacity) raises
+ * Control::apply_failed and the same step falls back to k_build, which rebuilds everything
+ * from the slab; both routes produce identical structures (tests/test_gpu_incremental.py).
+ */
+#include "mgl_base2.h"
+
+#define MGL_APPLY_CAP 8192u   /* inserted / removed events per accepted neighbour */
+#define MGL_SUB_CAP 1024u     /* per context */
+#define MGL_SPAN_CAP 4096u    /* rewritten chain entries per context */
+#define MGL_PIECE_CAP 160u
+
+struct ApplyBuf {
+	uint32_t* hdr;      /* [0] n_ins [1] n_rem [2] n_tctx [3] first journal position */
+	uint16_t* ins_key;  /* ctx | bit << 15 */
+	uint32_t* ins_pos;
+	uint16_t* rem_key;
+	uint32_t* rem_pos;
+	uint16_t* tctx;
+	uint32_t* scratch_pos; /* per workgroup: scratch_stride entries */
+	uint16_t* scratch_ev;
+	uint32_t scratch_stride;
+};
+
+__device__ __forceinline__ void bit_write(uint64_t* arr, uint32_t pos, bool on)
+{
+	const uint64_t m = 1ull << (pos & 63u);
+	uint64_t v = arr[pos >> 6];
+	v = on ? (v | m) : (v & ~m);
+	arr[pos >> 6] = v;
+}
+/* special bitmap with its two summary levels (lane 0 only) */
+__device__ __forceinline__ void special_write(const Base2& b, uint32_t pos, bool on)
+{
+	const uint32_t w = pos >> 6;
+	uint64_t v = b.sp0[w];
+	const uint64_t m = 1ull << (pos & 63u);
+	const uint64_t nv = on ? (v | m) : (v & ~m);
+	if (nv == v) return;
+	b.sp0[w] = nv;
+	if ((v != 0) == (nv != 0)) return;
+	const uint32_t u = w >> 6;
+	uint64_t v1 = b.sp1[u];
+	const uint64_t m1 = 1ull << (w & 63u);
+	const uint64_t nv1 = nv ? (v1 | m1) : (v1 & ~m1);
+	b.sp1[u] = nv1;
+	if ((v1 != 0) == (nv1 != 0)) return;
+	const uint32_t x = u >> 6;
+	const uint64_t m2 = 1ull << (u & 63u);
+	uint64_t v2 = b.sp2[x];
+	b.sp2[x] = nv1 ? (v2 | m2) : (v2 & ~m2);
+}
+
+__global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* ctl, NbrOut out, ApplyBuf ab)
+{
+	__shared__ uint32_t s_jpos[MGL_MAX_DIFFS];
+	__shared__ mgl_pk s_jnew[MGL_MAX_DIFFS];
+	__shared__ uint32_t s_ctxbits[512]; /* up to 16384 contexts */
+	const uint32_t lane = threadIdx.x;
+	if (!ctl->accepted_flag) return;
+	const uint32_t winner = ctl->winner;
+	const uint32_t nd = out.ndiffs[winner];
+	if (lane < nd) {
+		s_jpos[lane] = out.dpos[(size_t)winner * MGL_MAX_DIFFS + lane];
+		s_jnew[lane] = out.dnew[(size_t)winner * MGL_MAX_DIFFS + lane];
+	}
+	for (uint32_t i = lane; i < 512; i += 64) s_ctxbits[i] = 0;
+	wave_sync();
+	const uint32_t t = s_jpos[0], last_j = s_jpos[nd - 1];
+
+	mgl_wstate nb = uni_state(base_state_at(b, t));
+	mgl_wstate bs = nb;
+	Win win; win.base = 0xFFFFFFFFu; win.pk = 0; win.byte = 0;
+	uint32_t n_ins = 0, n_rem = 0;
+	int32_t dpackets = 0;
+	bool failed = false;
+	uint32_t ji = 0; /* next journal entry (positions ascending) */
+	uint32_t guard = 0;
+	while (nb.pos < c.n || bs.pos < c.n) {
+		if (++guard > (1u << 20)) { failed = true; break; }
+		if (nb.pos == bs.pos) {
+			const bool same_ctx = nb.ctx_state == bs.ctx_state;
+			const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
+			                    nb.dists[3] == bs.dists[3];
+			if (same_ctx && same_d && nb.pos > last_j) break;
+			if (same_ctx && nb.ctx_state < 7) {
+				/* plain literals code identically: skip to the next special or journal position */
+				uint32_t s = uni(sp_find_next(b, nb.pos));
+				if (s == MGL_POS_INF || s > c.n) s = c.n;
+				while (ji < nd && s_jpos[ji] < nb.pos) ji++;
+				if (ji < nd && s_jpos[ji] < s) s = s_jpos[ji];
+				if (s > nb.pos) {
+					const uint32_t cs = lit_steps(nb.ctx_state, s - nb.pos);
+					nb.pos = bs.pos = s; nb.ctx_state = bs.ctx_state = cs;
+					continue;
+				}
+			}
+		}
+		if (nb.pos <= bs.pos && nb.pos < c.n) {
+			const uint32_t p = nb.pos;
+			win_cover(win, c, b.slab, p, lane);
+			const mgl_pk old_at_p = win_pk(win, p);
+			while (ji < nd && s_jpos[ji] < p) ji++;
+			const mgl_pk pk = (ji < nd && s_jpos[ji] == p) ? s_jnew[ji] : old_at_p;
+			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
+			mgl_plan npl;
+			plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+			const bool paired = bs.pos == p;
+			bool cancelled = false;
+			mgl_plan bpl;
+			uint32_t btype = 0, bdist = 0, blen = 0;
+			if (paired) {
+				btype = mgl_pk_type(old_at_p); bdist = mgl_pk_dist(old_at_p); blen = mgl_pk_len(old_at_p);
+				plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
+				cancelled = old_at_p == pk && nb.ctx_state == bs.ctx_state &&
+				            (ntype != MGL_LITERAL || nb.ctx_state < 7 || npl.match_byte == bpl.match_byte);
+			}
+			/* base structures at p: on the new walk; special iff not a literal */
+			if (lane == 0) {
+				if (!paired) bit_write(b.onwalk, p, true);
+				special_write(b, p, ntype != MGL_LITERAL);
+			}
+			if (ntype != MGL_LITERAL && lane < 8) {
+				const uint32_t v = lane == 0 ? nb.ctx_state : lane == 1 ? nb.dists[0] : lane == 2 ? nb.dists[1]
+				                 : lane == 3 ? nb.dists[2] : lane == 4 ? nb.dists[3] : 0u;
+				b.sp_state[(size_t)p * 8 + lane] = v;
+			}
+			if (!cancelled) {
+				if (n_ins + npl.nev > MGL_APPLY_CAP || (paired && n_rem + bpl.nev > MGL_APPLY_CAP)) { failed = true; break; }
+				if (lane < npl.nev) {
+					uint32_t ctx, bit;
+					mgl_plan_event(&npl, lane, &ctx, &bit);
+					ab.ins_key[n_ins + lane] = (uint16_t)(ctx | (bit << 15));
+					ab.ins_pos[n_ins + lane] = p;
+					atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+				}
+				n_ins += npl.nev;
+				if (paired) {
+					if (lane < bpl.nev) {
+						uint32_t ctx, bit;
+						mgl_plan_event(&bpl, lane, &ctx, &bit);
+						ab.rem_key[n_rem + lane] = (uint16_t)ctx;
+						ab.rem_pos[n_rem + lane] = p;
+						atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+					}
+					n_rem += bpl.nev;
+				}
+			}
+			dpackets += paired ? 0 : 1;
+			if (paired) mgl_advance(&bs, btype, bdist, blen);
+			mgl_advance(&nb, ntype, ndist, nlen);
+		} else {
+			/* an old packet that is not on the new walk any more */
+			const uint32_t q = bs.pos;
+			win_cover(win, c, b.slab, q, lane);
+			const mgl_pk bpk = win_pk(win, q);
+			const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
+			mgl_plan bpl;
+			plan_at(c, bs, btype, bdist, blen, win_byte(win, q), bpl);
+			if (n_rem + bpl.nev > MGL_APPLY_CAP) { failed = true; break; }
+			if (lane < bpl.nev) {
+				uint32_t ctx, bit;
+				mgl_plan_event(&bpl, lane, &ctx, &bit);
+				ab.rem_key[n_rem + lane] = (uint16_t)ctx;
+				ab.rem_pos[n_rem + lane] = q;
+				atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+			}
+			n_rem += bpl.nev;
+			if (lane == 0) { bit_write(b.onwalk, q, false); special_write(b, q, false); }
+			dpackets -= 1;
+			mgl_advance(&bs, btype, bdist, blen);
+		}
+	}
+	wave_sync();
+	/* the journal goes into the slab (main.c keeps the mutated slab on accept) */
+	if (lane < nd) b.slab[s_jpos[lane]] = s_jnew[lane];
+	/* touched contexts, ascending */
+	uint32_t nt = 0;
+	for (uint32_t wbase = 0; wbase < 512; wbase += 64) {
+		const uint32_t word = s_ctxbits[wbase + lane];
+		const uint32_t cntl = (uint32_t)__popc(word);
+		uint32_t incl = cntl;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t tmp = (uint32_t)__shfl_up((int)incl, o, 64);
+			if ((int)lane >= o) incl += tmp;
+		}
+		uint32_t at = nt + incl - cntl;
+		uint32_t wv = word;
+		while (wv) {
+			const uint32_t bit = (uint32_t)__ffs((int)wv) - 1u;
+			ab.tctx[at++] = (uint16_t)(((wbase + lane) << 5) + bit);
+			wv &= wv - 1u;
+		}
+		nt += (uint32_t)__shfl((int)incl, 63, 64);
+	}
+	if (lane == 0) {
+		ab.hdr[0] = n_ins; ab.hdr[1] = n_rem; ab.hdr[2] = failed ? 0u : nt; ab.hdr[3] = t;
+		ctl->packets = (uint64_t)((int64_t)ctl->packets + dpackets);
+		ctl->rebuild_cost = ctl->cur_cost; /* exact cost of the new base */
+		if (failed) ctl->apply_failed = 1;
+	}
+}
+
+/* first packet start at or after checkpoint ck's boundary (new walk), or MGL_POS_INF */
+__device__ __forceinline__ uint32_t ckpt_boundary(const Base2& b, uint32_t ck)
+{
+	uint32_t w = ck;
+	while (w < b.nw0) {
+		const uint64_t v = b.onwalk[w];
+		if (v) return (w << 6) + ctz64(v);
+		w++;
+	}
+	return MGL_POS_INF;
+}
+
+struct Piece {
+	uint32_t dst;   /* index in the chain, relative to k0 */
+	uint32_t src;   /* index in span[] or in the scratch copy (relative to k0) */
+	uint32_t count;
+	uint32_t from_span;
+};
+
+__global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control* ctl, ApplyBuf ab)
+{
+	__shared__ uint32_t s_ipos[MGL_SUB_CAP];
+	__shared__ uint16_t s_ibit[MGL_SUB_CAP];
+	__shared__ uint32_t s_rpos[MGL_SUB_CAP];
+	__shared__ uint32_t s_span_pos[MGL_SPAN_CAP];
+	__shared__ uint16_t s_span_ev[MGL_SPAN_CAP];
+	__shared__ Piece s_piece[MGL_PIECE_CAP];
+	/* checkpoint patch segments: positions (lo, hi] take their value from span[first..last) */
+	__shared__ uint32_t s_seg_lo[MGL_PIECE_CAP], s_seg_hi[MGL_PIECE_CAP], s_seg_first[MGL_PIECE_CAP], s_seg_last[MGL_PIECE_CAP];
+	__shared__ uint16_t s_seg_endp[MGL_PIECE_CAP];
+	__shared__ uint32_t s_wcount[8];
+	__shared__ uint32_t s_ni, s_nr, s_npiece, s_nseg, s_k0, s_newtail, s_oldlen, s_fail, s_newlen;
+	if (!ctl->accepted_flag || ctl->apply_failed) return;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+	const uint32_t n_ins = ab.hdr[0], n_rem = ab.hdr[1], nt = ab.hdr[2];
+	uint32_t* my_spos = ab.scratch_pos + (size_t)blockIdx.x * ab.scratch_stride;
+	uint16_t* my_sev = ab.scratch_ev + (size_t)blockIdx.x * ab.scratch_stride;
+
+	for (uint32_t ti = blockIdx.x; ti < nt; ti += gridDim.x) {
+		const uint32_t cx = ab.tctx[ti];
+		__syncthreads();
+		if (tid == 0) { s_ni = 0; s_nr = 0; s_fail = 0; }
+		__syncthreads();
+		/* ---- 1. this context's inserted / removed events, order preserved */
+		for (int pass = 0; pass < 2; pass++) {
+			const uint32_t m = pass == 0 ? n_ins : n_rem;
+			for (uint32_t base = 0; base < m; base += 256) {
+				const uint32_t e = base + tid;
+				bool hit = false;
+				uint32_t key = 0, pos = 0;
+				if (e < m) {
+					key = pass == 0 ? ab.ins_key[e] : ab.rem_key[e];
+					pos = pass == 0 ? ab.ins_pos[e] : ab.rem_pos[e];
+					hit = (key & 0x7FFFu) == cx;
+				}
+				const unsigned long long mask = __ballot(hit);
+				if (lane == 0) s_wcount[wid] = (uint32_t)__popcll(mask);
+				__syncthreads();
+				uint32_t before = pass == 0 ? s_ni : s_nr;
+				for (uint32_t w = 0; w < wid; w++) before += s_wcount[w];
+				const uint32_t idx = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+				if (hit) {
+					if (idx < MGL_SUB_CAP) {
+						if (pass == 0) { s_ipos[idx] = pos; s_ibit[idx] = (uint16_t)(key >> 15); }
+						else s_rpos[idx] = pos;
+					} else s_fail = 1;
+				}
+				__syncthreads();
+				if (tid == 0) {
+					const uint32_t tot = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+					if (pass == 0) s_ni += tot; else s_nr += tot;
+				}
+				__syncthreads();
+			}
+		}
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+
+		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
+		uint32_t* cpos = b.ch_pos + off;
+		uint16_t* cev = b.ch_ev + off;
+		/* ---- 2. re-simulate (one thread): new entries, pieces, checkpoint segments */
+		if (tid == 0) {
+			const uint32_t ni = s_ni, nr = s_nr;
+			uint32_t ii = 0, ri = 0, ns = 0, np = 0, nseg = 0;
+			const uint32_t x0 = (ni ? s_ipos[0] : MGL_POS_INF) < (nr ? s_rpos[0] : MGL_POS_INF) ? s_ipos[0] : s_rpos[0];
+			const uint32_t k0 = chain_lower_bound(cpos, len, x0);
+			uint32_t k = k0, dst = 0;
+			uint32_t p = cev[k] & 0x7FFu;
+			bool fail = false;
+			uint32_t seg_first = 0, seg_lo = x0;
+			bool in_seg = true; /* a segment = a stretch where the new trajectory differs / entries change */
+			for (;;) {
+				const bool pending = ii < ni || ri < nr;
+				const uint32_t bpos = cpos[k];
+				const uint32_t ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF;
+				if (ipos < bpos) {
+					if (ns >= MGL_SPAN_CAP) { fail = true; break; }
+					s_span_pos[ns] = ipos; s_span_ev[ns] = (uint16_t)((s_ibit[ii] << 15) | p); ns++;
+					p = mgl_prob_update(p, s_ibit[ii]);
+					ii++;
+					continue;
+				}
+				if (bpos == MGL_POS_INF) break; /* reached the sentinel */
+				const uint32_t ev = cev[k];
+				const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+				const uint32_t rposn = ri < nr ? s_rpos[ri] : MGL_POS_INF;
+				const uint32_t nxt = ipos < rposn ? ipos : rposn;
+				if (p == bp && (!pending || nxt > bpos)) {
+					/* re-coupled at old entry k (which itself stays): close the segment */
+					if (nseg >= MGL_PIECE_CAP || np + 2 > MGL_PIECE_CAP) { fail = true; break; }
+					s_seg_lo[nseg] = seg_lo; s_seg_hi[nseg] = bpos; s_seg_first[nseg] = seg_first; s_seg_last[nseg] = ns;
+					s_seg_endp[nseg] = (uint16_t)p; nseg++;
+					s_piece[np].dst = dst; s_piece[np].src = seg_first; s_piece[np].count = ns - seg_first; s_piece[np].from_span = 1; np++;
+					dst += ns - seg_first;
+					in_seg = false;
+					if (!pending) break;
+					/* unchanged stretch up to the next change of this context */
+					const uint32_t k2 = k + chain_lower_bound(cpos + k, len - k, nxt);
+					s_piece[np].dst = dst; s_piece[np].src = k - k0; s_piece[np].count = k2 - k; s_piece[np].from_span = 0; np++;
+					dst += k2 - k;
+					k = k2;
+					p = cev[k] & 0x7FFu;
+					seg_first = ns; seg_lo = nxt; in_seg = true;
+					continue;
+				}
+				if (ri < nr && s_rpos[ri] == bpos) {
+					ri++;
+				} else {
+					if (ns >= MGL_SPAN_CAP) { fail = true; break; }
+					s_span_pos[ns] = bpos; s_span_ev[ns] = (uint16_t)((bb << 15) | p); ns++;
+					p = mgl_prob_update(p, bb);
+				}
+				k++;
+			}
+			if (!fail && in_seg) {
+				/* ran into the sentinel un-coupled: the last segment reaches the end of the file */
+				if (nseg >= MGL_PIECE_CAP || np + 1 > MGL_PIECE_CAP) fail = true;
+				else {
+					s_seg_lo[nseg] = seg_lo; s_seg_hi[nseg] = MGL_POS_INF; s_seg_first[nseg] = seg_first; s_seg_last[nseg] = ns;
+					s_seg_endp[nseg] = (uint16_t)p; nseg++;
+					s_piece[np].dst = dst; s_piece[np].src = seg_first; s_piece[np].count = ns - seg_first; s_piece[np].from_span = 1; np++;
+					dst += ns - seg_first;
+				}
+			}
+			/* k = first old entry that stays (re-coupled), or the sentinel */
+			const uint32_t tail = len + 1 - k;   /* entries [k, len] incl. the sentinel */
+			const uint32_t newlen = k0 + dst + (len - k);
+			if (newlen + 1 > cap || (len + 1 - k0) > ab.scratch_stride) fail = true;
+			if (!fail) {
+				s_piece[np].dst = dst; s_piece[np].src = k - k0; s_piece[np].count = tail; s_piece[np].from_span = 0; np++;
+				/* an un-coupled end changes the context's final probability: the sentinel */
+			}
+			s_npiece = np; s_nseg = nseg; s_k0 = k0; s_oldlen = len; s_newlen = newlen; s_fail = fail ? 1u : 0u;
+			s_newtail = (cpos[k] == MGL_POS_INF && in_seg) ? (p | 0x10000u) : 0u; /* new sentinel value if un-coupled */
+		}
+		__syncthreads();
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		const uint32_t k0 = s_k0, oldlen = s_oldlen;
+		/* ---- 3. copy the old region [k0, len] aside, then write the pieces back */
+		for (uint32_t i = tid; i < oldlen + 1 - k0; i += 256) { my_spos[i] = cpos[k0 + i]; my_sev[i] = cev[k0 + i]; }
+		__syncthreads();
+		for (uint32_t pi = 0; pi < s_npiece; pi++) {
+			const Piece pc = s_piece[pi];
+			for (uint32_t i = tid; i < pc.count; i += 256) {
+				if (pc.from_span) { cpos[k0 + pc.dst + i] = s_span_pos[pc.src + i]; cev[k0 + pc.dst + i] = s_span_ev[pc.src + i]; }
+				else { cpos[k0 + pc.dst + i] = my_spos[pc.src + i]; cev[k0 + pc.dst + i] = my_sev[pc.src + i]; }
+			}
+		}
+		__syncthreads();
+		if (tid == 0) {
+			b.ch_len[cx] = s_newlen;
+			if (s_newtail & 0x10000u) cev[s_newlen] = (uint16_t)(s_newtail & 0x7FFu);
+		}
+		/* ---- 4. dense checkpoints: this context's value wherever its trajectory changed */
+		for (uint32_t sg = 0; sg < s_nseg; sg++) {
+			const uint32_t lo = s_seg_lo[sg], hi = s_seg_hi[sg];
+			const uint32_t first = s_seg_first[sg], last = s_seg_last[sg];
+			/* a boundary can lie behind a packet that starts up to 272 bytes before lo */
+			const uint32_t ck_lo = (lo > MGL_MAX_MATCH ? lo - MGL_MAX_MATCH : 0u) >> MGL_CK2_SHIFT;
+			const uint32_t ck_hi = hi == MGL_POS_INF ? b.nck : ((hi >> MGL_CK2_SHIFT) + 1u < b.nck ? (hi >> MGL_CK2_SHIFT) + 1u : b.nck);
+			for (uint32_t ck = ck_lo + tid; ck < ck_hi; ck += 256) {
+				const uint32_t P = ckpt_boundary(b, ck); /* MGL_POS_INF: behind the last packet = final model */
+				if (P <= lo || P > hi) continue;     /* value there is the old one */
+				/* probability before the first new event of this segment at or after P */
+				uint32_t a = first, z = last;
+				while (a < z) { const uint32_t mid = (a + z) >> 1; if (s_span_pos[mid] < P) a = mid + 1; else z = mid; }
+				const uint16_t v = a < last ? (uint16_t)(s_span_ev[a] & 0x7FFu) : s_seg_endp[sg];
+				b.ck_probs[(size_t)ck * b.ck_elems + cx] = v;
+			}
+		}
+	}
+}
+
+/* decide-only variant of the step's tail: flags for k_build's conditional run are reset there */
+__global__ void k_step_end(Control* ctl)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) { ctl->accepted_flag = 0; ctl->apply_failed = 0; }
+}

@@ -126,3 +126,55 @@ def test_engines_agree_on_c2_neighbours():
     assert ca == cb and (a == b).all()
     inc.close()
     full.close()
+
+
+def canonical_base(sa, slab):
+    """The incremental engine's base structures in an offset-independent form."""
+    n, total = sa.n, sa.nprobs
+    off = sa.debug_dump(0, np.uint32)
+    ln = sa.debug_dump(1, np.uint32)
+    cap = sa.debug_dump(8, np.uint32)
+    cpos = sa.debug_dump(2, np.uint32)
+    cev = sa.debug_dump(3, np.uint16)
+    chains = []
+    for c in range(total):
+        k, m = int(off[c]), int(ln[c])
+        assert m + 1 <= cap[c], c
+        chains.append((cpos[k:k + m + 1].copy(), cev[k:k + m + 1].copy()))
+    on = np.unpackbits(sa.debug_dump(4, np.uint64).view(np.uint8), bitorder="little")[:n].astype(bool)
+    sp = np.unpackbits(sa.debug_dump(5, np.uint64).view(np.uint8), bitorder="little")[:n].astype(bool)
+    st = sa.debug_dump(6, np.uint32).reshape(n, 8)[:, :5]
+    ck = sa.debug_dump(7, np.uint16).reshape(-1, (total + 7) // 8 * 8)[:, :total]
+    return dict(chains=chains, on=on, sp=sp, st=st[sp], ck=ck)
+
+
+def assert_same_base(a, b, what):
+    assert (a["on"] == b["on"]).all(), what
+    assert (a["sp"] == b["sp"]).all(), what
+    assert (a["st"] == b["st"]).all(), (what, np.nonzero((a["st"] != b["st"]).any(axis=1))[0][:5])
+    for c, (x, y) in enumerate(zip(a["chains"], b["chains"])):
+        assert len(x[0]) == len(y[0]) and (x[0] == y[0]).all() and (x[1] == y[1]).all(), (what, "chain", c)
+    bad = np.nonzero((a["ck"] != b["ck"]).any(axis=1))[0]
+    assert len(bad) == 0, (what, "checkpoints", bad[:5], np.nonzero(a["ck"][bad[0]] != b["ck"][bad[0]])[0][:5])
+
+
+@pytest.mark.parametrize("name,K,steps", [("lorem4k", 64, 120), ("enwik3k", 96, 150), ("reps", 48, 120), ("zeros600", 32, 60)])
+def test_incremental_accept_equals_rebuild(name, K, steps, golden, golden_input):
+    """After every accepted step the incrementally maintained base (bitmaps, special-state
+    records, chains, dense checkpoints) is identical to one rebuilt from the slab."""
+    data = golden_input(name)
+    inc = binding.SA(data, neighbours_per_step=K, seed=5, iters_per_epoch=steps)
+    ref = binding.SA(data, neighbours_per_step=8, seed=5)
+    o = Oracle(data, dict_limit=0x400000)
+    accepted = 0
+    for s in range(steps):
+        st = inc.run(1)
+        accepted += st["accepted"]
+        if st["accepted"] and (s < 30 or s % 7 == 0):
+            cur, cost = inc.current()
+            assert cost == o.cost_slab(cur.astype(literal_slab(1).dtype))["total"], s
+            ref.set_slab(cur)
+            assert_same_base(canonical_base(inc, cur), canonical_base(ref, cur), (name, s))
+    assert accepted > 5
+    inc.close()
+    ref.close()

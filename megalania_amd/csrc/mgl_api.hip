@@ -81,6 +81,8 @@ struct mgl_sa {
 	uint32_t* d_todo;       /* [0] = count, [1..K] = neighbour indices for the full-walk fallback */
 	uint32_t per_wave2, waves_per_block2, nbr2_lds, build_lds;
 	size_t b2_bytes;
+	BigScratch big;
+	uint32_t* d_todo2;
 	ApplyBuf ab;
 	uint32_t apply_blocks;
 	bool incremental_apply;
@@ -155,15 +157,21 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 		return MGL_OK;
 	}
 	HIPCHK(hipMemsetAsync(sa->d_todo, 0, sizeof(uint32_t), sa->stream));
+	HIPCHK(hipMemsetAsync(sa->d_todo2, 0, sizeof(uint32_t), sa->stream));
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
-	hipLaunchKernelGGL(k_neighbours2, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx, sa->b2,
-	                   sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1,
-	                   sa->d_todo, sa->d_prof);
-	/* neighbours that did not fit the LDS change lists: exact full walk from byte 0 */
-	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
+	hipLaunchKernelGGL(k_neighbours2<false>, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1, sa->d_todo,
+	                   sa->d_prof, sa->big);
+	/* the few whose change lists overflowed LDS: same kernel, lists in global scratch */
+	const uint32_t bigblocks = (MGL_BIG_SLOTS + sa->waves_per_block2 - 1) / sa->waves_per_block2;
+	hipLaunchKernelGGL(k_neighbours2<true>, dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2 + 1, sa->d_todo2,
+	                   (unsigned long long*)nullptr, sa->big);
+	/* and whatever overflowed even that: exact full walk from byte 0 */
+	const uint32_t blocks = (MGL_BIG_SLOTS + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
-	                   (const uint32_t*)(sa->d_todo + 1), (const uint32_t*)sa->d_todo);
+	                   (const uint32_t*)(sa->d_todo2 + 1), (const uint32_t*)sa->d_todo2);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -198,6 +206,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->b2.sp0); dfree(sa->b2.sp1); dfree(sa->b2.sp2); dfree(sa->b2.sp_state); dfree(sa->b2.ck_probs);
 	dfree(sa->b2.ch_off); dfree(sa->b2.ch_len); dfree(sa->b2.ch_cap); dfree(sa->b2.ch_pos); dfree(sa->b2.ch_ev);
 	dfree(sa->b2.pool_top); dfree(sa->d_todo); dfree(sa->d_prof);
+	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
+	dfree(sa->d_todo2);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
@@ -286,7 +296,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		b.nw2 = (b.nw1 + 63) / 64;
 		b.nck = b.nw0;
 		b.ck_elems = ckpt_elems;
-		b.pool_cap = (uint32_t)(14 * n + (size_t)L.total * 40 + 4096);
+		b.pool_cap = (uint32_t)(24 * n + (size_t)L.total * 272 + 4096);
 		size_t bytes = 0;
 		HIPCHK(hipMalloc(&b.sp0, sizeof(uint64_t) * (b.nw0 + 64))); bytes += sizeof(uint64_t) * (b.nw0 + 64);
 		HIPCHK(hipMalloc(&b.sp1, sizeof(uint64_t) * (b.nw1 + 64)));
@@ -325,12 +335,36 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
 			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
 		}
-		sa->per_wave2 = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) + MGL_UCTX_CAP * 2u;
-		sa->waves_per_block2 = 4;
-		while (sa->waves_per_block2 > 1 && 4096u + sa->waves_per_block2 * sa->per_wave2 > 160u * 1024u) sa->waves_per_block2--;
+		sa->per_wave2 = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) +
+		                2u * MGL_CHG_CAP * 2u + ((((L.total + 31u) >> 5) * 4u + 15u) & ~15u);
+		{
+			BigScratch& g = sa->big;
+			memset(&g, 0, sizeof g);
+			g.cap = MGL_BIG_CAP; g.uctx_cap = ckpt_elems; g.slots = MGL_BIG_SLOTS;
+			HIPCHK(hipMalloc(&g.ins_key, sizeof(uint16_t) * (size_t)g.cap * g.slots));
+			HIPCHK(hipMalloc(&g.rem_key, sizeof(uint16_t) * (size_t)g.cap * g.slots));
+			HIPCHK(hipMalloc(&g.ins_pos, sizeof(uint32_t) * (size_t)g.cap * g.slots));
+			HIPCHK(hipMalloc(&g.rem_pos, sizeof(uint32_t) * (size_t)g.cap * g.slots));
+			HIPCHK(hipMalloc(&g.uctx, sizeof(uint16_t) * (size_t)g.uctx_cap * g.slots));
+			HIPCHK(hipMalloc(&sa->d_todo2, sizeof(uint32_t) * (K + 1)));
+			HIPCHK(hipMemset(sa->d_todo2, 0, sizeof(uint32_t) * (K + 1)));
+		}
+		/* waves per workgroup that packs the most waves into a CU's 160 KiB of LDS */
+		{
+			uint32_t best_w = 1, best_total = 0;
+			for (uint32_t w = 1; w <= 8; w++) {
+				const uint32_t bytes = 4096u + w * sa->per_wave2;
+				if (bytes > 160u * 1024u) break;
+				const uint32_t tot = (160u * 1024u / bytes) * w;
+				if (tot > best_total) { best_total = tot; best_w = w; }
+			}
+			sa->waves_per_block2 = best_w;
+		}
 		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
 		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;
-		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		sa->big.todo_in = sa->d_todo + 1; sa->big.todo_in_count = sa->d_todo;
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
 

@@ -25,7 +25,8 @@
 #define MGL_CK2_SHIFT 6u
 #define MGL_POS_INF 0xFFFFFFFFu
 #define MGL_CHG_CAP 256u   /* inserted / removed events per neighbour kept in LDS */
-#define MGL_UCTX_CAP 128u  /* distinct touched contexts per neighbour */
+#define MGL_BIG_CAP 8192u   /* the same, per flagged neighbour, in the global scratch of the second pass */
+#define MGL_BIG_SLOTS 128u
 
 struct Base2 {
 	mgl_pk* slab;

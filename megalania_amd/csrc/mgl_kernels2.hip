@@ -113,12 +113,13 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 		const unsigned long long m = __ballot(nz);
 		if (lane == 0) b.sp2[v] = m;
 	}
-	/* chain offsets: capacity = len + len/2 + 33 rounded up to 8 (incl. the sentinel); lanes own contiguous context ranges */
+	/* chain offsets: capacity = 2 len + 257 rounded up to 8 (incl. the sentinel): room to grow before a
+	 * chain has to move (k_apply_chains); lanes own contiguous context ranges */
 	{
 		const uint32_t per = (total + 63u) / 64u;
 		const uint32_t lo = lane * per, hi = (lo + per) < total ? (lo + per) : total;
 		uint32_t sum = 0;
-		for (uint32_t i = lo; i < hi; i++) sum += (cnt[i] + (cnt[i] >> 1) + 33u + 7u) & ~7u;
+		for (uint32_t i = lo; i < hi; i++) sum += (2u * cnt[i] + 257u + 7u) & ~7u;
 		uint32_t incl = sum;
 		for (int o = 1; o < 64; o <<= 1) {
 			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 		}
 		uint32_t run = incl - sum;
 		for (uint32_t i = lo; i < hi; i++) {
-			const uint32_t cap = (cnt[i] + (cnt[i] >> 1) + 33u + 7u) & ~7u; /* multiple of 8: 16-byte aligned chains */
+			const uint32_t cap = (2u * cnt[i] + 257u + 7u) & ~7u; /* multiple of 8: 16-byte aligned chains */
 			off[i] = run;
 			b.ch_off[i] = run; b.ch_len[i] = cnt[i]; b.ch_cap[i] = cap;
 			run += cap;
@@ -218,7 +219,11 @@ struct Changes {
 	uint32_t* ins_pos;
 	uint16_t* rem_key; /* ctx */
 	uint32_t* rem_pos;
-	uint16_t* uctx;
+	uint16_t* uctx;     /* distinct touched contexts (scratch of chain_sim) */
+	uint32_t* ctxbits;  /* LDS bitmap over the probability contexts (scratch of chain_sim) */
+	uint32_t cap;       /* capacity of each list */
+	uint32_t uctx_cap;
+	uint32_t nbitwords;
 	uint32_t n_ins, n_rem; /* uniform */
 	int64_t direct;        /* (inserted - removed) direct-bit cost, uniform */
 	unsigned long long* dbg; /* diagnostic counters (MGL_F_PROFILE), else nullptr */
@@ -230,7 +235,7 @@ template <bool INS>
 __device__ __forceinline__ void changes_add(Changes& ch, const mgl_plan& pl, uint32_t pos, uint32_t lane)
 {
 	uint32_t& n = INS ? ch.n_ins : ch.n_rem;
-	if (n + pl.nev > MGL_CHG_CAP) { ch.overflow = true; return; }
+	if (n + pl.nev > ch.cap) { ch.overflow = true; return; }
 	if (lane < pl.nev) {
 		uint32_t ctx, bit;
 		mgl_plan_event(&pl, lane, &ctx, &bit);
@@ -254,26 +259,32 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 {
 	const uint32_t m = ch.n_ins + ch.n_rem;
 	wave_sync();
-	/* distinct contexts, in first-appearance order */
+	/* distinct contexts through a bitmap in LDS, then listed in ascending order */
+	for (uint32_t i = lane; i < ch.nbitwords; i += 64) ch.ctxbits[i] = 0;
+	wave_sync();
+	for (uint32_t e = lane; e < m; e += 64) {
+		const uint32_t key = e < ch.n_ins ? (ch.ins_key[e] & 0x7FFFu) : ch.rem_key[e - ch.n_ins];
+		atomicOr(&ch.ctxbits[key >> 5], 1u << (key & 31u));
+	}
+	wave_sync();
 	uint32_t nu = 0;
-	for (uint32_t base = 0; base < m; base += 64) {
-		const uint32_t e = base + lane;
-		bool first = false;
-		uint32_t key = 0;
-		if (e < m) {
-			key = e < ch.n_ins ? (ch.ins_key[e] & 0x7FFFu) : ch.rem_key[e - ch.n_ins];
-			first = true;
-			for (uint32_t q = 0; q < e && first; q++) {
-				const uint32_t kq = q < ch.n_ins ? (ch.ins_key[q] & 0x7FFFu) : ch.rem_key[q - ch.n_ins];
-				first = kq != key;
-			}
+	for (uint32_t wbase = 0; wbase < ch.nbitwords; wbase += 64) {
+		const uint32_t word = wbase + lane < ch.nbitwords ? ch.ctxbits[wbase + lane] : 0u;
+		const uint32_t cntl = (uint32_t)__popc(word);
+		uint32_t incl = cntl;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t tmp = (uint32_t)__shfl_up((int)incl, o, 64);
+			if ((int)lane >= o) incl += tmp;
 		}
-		const unsigned long long mask = __ballot(first);
-		const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-		const uint32_t add = (uint32_t)__popcll(mask);
-		if (nu + add > MGL_UCTX_CAP) { *too_many = true; return 0; }
-		if (first) ch.uctx[nu + rank] = (uint16_t)key;
-		nu += add;
+		const uint32_t chunk = (uint32_t)__shfl((int)incl, 63, 64);
+		if (nu + chunk > ch.uctx_cap) { *too_many = true; return 0; }
+		uint32_t at = nu + incl - cntl;
+		uint32_t wv = word;
+		while (wv) {
+			ch.uctx[at++] = (uint16_t)(((wbase + lane) << 5) + ((uint32_t)__ffs((int)wv) - 1u));
+			wv &= wv - 1u;
+		}
+		nu += chunk;
 	}
 	wave_sync();
 	int64_t delta = 0;
@@ -449,16 +460,34 @@ __device__ __forceinline__ void walk_from_state(Walk& w, const mgl_wstate& st)
 	w.st = st;
 }
 
-__global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
+/* BIG = false: the regular launch, change lists in LDS (MGL_CHG_CAP events each).
+ * BIG = true: second chance for the few neighbours whose lists overflowed LDS: same code, lists
+ * in a per-neighbour global scratch area (big.cap events each); what overflows even that goes
+ * to the full-walk kernel. */
+struct BigScratch {
+	uint16_t* ins_key; uint32_t* ins_pos; uint16_t* rem_key; uint32_t* rem_pos; uint16_t* uctx;
+	uint32_t cap, uctx_cap, slots;
+	const uint32_t* todo_in; const uint32_t* todo_in_count;
+};
+template <bool BIG>
+__global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
-                                                     uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc)
+                                                     uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
+                                                     BigScratch big)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	const uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	uint32_t slot = 0;
+	if (BIG) {
+		slot = j;
+		const uint32_t nflag = *big.todo_in_count;
+		if (slot >= nflag) return;
+		j = uni(big.todo_in[slot]);
+	}
 	if (j >= K) return;
 	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
 	uint16_t* probs = (uint16_t*)mine;
@@ -474,6 +503,19 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, Control*
 	ch.ins_key = (uint16_t*)(ch.rem_pos + MGL_CHG_CAP);
 	ch.rem_key = ch.ins_key + MGL_CHG_CAP;
 	ch.uctx = ch.rem_key + MGL_CHG_CAP;
+	ch.ctxbits = (uint32_t*)(ch.uctx + 2 * MGL_CHG_CAP);
+	ch.cap = MGL_CHG_CAP; ch.uctx_cap = 2 * MGL_CHG_CAP;
+	ch.nbitwords = (c.L.total + 31u) >> 5;
+	if (BIG) {
+		if (slot >= big.slots) { /* more flagged neighbours than scratch slots: full walk */
+			if (lane == 0) { const uint32_t s2 = atomicAdd(todo_count, 1u); todo[s2] = j; }
+			return;
+		}
+		ch.ins_key = big.ins_key + (size_t)slot * big.cap; ch.ins_pos = big.ins_pos + (size_t)slot * big.cap;
+		ch.rem_key = big.rem_key + (size_t)slot * big.cap; ch.rem_pos = big.rem_pos + (size_t)slot * big.cap;
+		ch.uctx = big.uctx + (size_t)slot * big.uctx_cap;
+		ch.cap = big.cap; ch.uctx_cap = big.uctx_cap;
+	}
 	ch.n_ins = ch.n_rem = 0; ch.direct = 0; ch.overflow = false;
 	bool too_many = false;
 
@@ -554,7 +596,7 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, Control*
 	bool first_packet = true;
 	uint32_t guard = 0;
 	while (nb.pos < c.n || bs.pos < c.n) {
-		if (ch.overflow || jn.overflow || too_many || ++guard > 4096u) { ch.overflow = true; break; }
+		if (ch.overflow || jn.overflow || too_many || ++guard > (BIG ? (1u << 20) : 4096u)) { ch.overflow = true; break; }
 		if (!first_packet && nb.pos == bs.pos && count >= 3) {
 			const bool same_ctx = nb.ctx_state == bs.ctx_state;
 			const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
@@ -667,7 +709,7 @@ __global__ void __launch_bounds__(256) k_neighbours2(DevCtx c, Base2 b, Control*
 		if (lane == 0) {
 			const uint32_t slot = atomicAdd(todo_count, 1u);
 			todo[slot] = j;
-			atomicAdd((unsigned long long*)&ctl->fallback_nbrs, 1ull);
+			if (BIG) atomicAdd((unsigned long long*)&ctl->fallback_nbrs, 1ull);
 			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
 		}
 		return;

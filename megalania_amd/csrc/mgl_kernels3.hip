@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 	__shared__ uint32_t s_seg_lo[MGL_PIECE_CAP], s_seg_hi[MGL_PIECE_CAP], s_seg_first[MGL_PIECE_CAP], s_seg_last[MGL_PIECE_CAP];
 	__shared__ uint16_t s_seg_endp[MGL_PIECE_CAP];
 	__shared__ uint32_t s_wcount[8];
-	__shared__ uint32_t s_ni, s_nr, s_npiece, s_nseg, s_k0, s_newtail, s_oldlen, s_fail, s_newlen;
+	__shared__ uint32_t s_ni, s_nr, s_npiece, s_nseg, s_k0, s_newtail, s_oldlen, s_fail, s_newlen, s_newoff, s_newcap;
 	if (!ctl->accepted_flag || ctl->apply_failed) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
 	const uint32_t n_ins = ab.hdr[0], n_rem = ab.hdr[1], nt = ab.hdr[2];
@@ -360,7 +360,15 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 			/* k = first old entry that stays (re-coupled), or the sentinel */
 			const uint32_t tail = len + 1 - k;   /* entries [k, len] incl. the sentinel */
 			const uint32_t newlen = k0 + dst + (len - k);
-			if (newlen + 1 > cap || (len + 1 - k0) > ab.scratch_stride) fail = true;
+			uint32_t newoff = off, newcap = cap;
+			if (!fail && newlen + 1 > cap) {
+				/* the chain outgrew its slot: move it to fresh space at the top of the pool */
+				newcap = (2u * (newlen + 1u) + 256u + 7u) & ~7u;
+				newoff = atomicAdd(b.pool_top, newcap);
+				if (newoff + newcap > b.pool_cap) fail = true; /* pool exhausted: k_build compacts */
+			}
+			if ((len + 1 - k0) > ab.scratch_stride) fail = true;
+			s_newoff = newoff; s_newcap = newcap;
 			if (!fail) {
 				s_piece[np].dst = dst; s_piece[np].src = k - k0; s_piece[np].count = tail; s_piece[np].from_span = 0; np++;
 				/* an un-coupled end changes the context's final probability: the sentinel */
@@ -371,20 +379,26 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 		__syncthreads();
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
 		const uint32_t k0 = s_k0, oldlen = s_oldlen;
-		/* ---- 3. copy the old region [k0, len] aside, then write the pieces back */
+		/* ---- 3. copy the old region [k0, len] aside, then write the pieces back (or, when the
+		 * chain moves, write prefix and pieces straight to the new slot) */
+		const bool moved = s_newoff != off;
+		uint32_t* npos = b.ch_pos + s_newoff;
+		uint16_t* nev = b.ch_ev + s_newoff;
 		for (uint32_t i = tid; i < oldlen + 1 - k0; i += 256) { my_spos[i] = cpos[k0 + i]; my_sev[i] = cev[k0 + i]; }
+		if (moved) for (uint32_t i = tid; i < k0; i += 256) { npos[i] = cpos[i]; nev[i] = cev[i]; }
 		__syncthreads();
 		for (uint32_t pi = 0; pi < s_npiece; pi++) {
 			const Piece pc = s_piece[pi];
 			for (uint32_t i = tid; i < pc.count; i += 256) {
-				if (pc.from_span) { cpos[k0 + pc.dst + i] = s_span_pos[pc.src + i]; cev[k0 + pc.dst + i] = s_span_ev[pc.src + i]; }
-				else { cpos[k0 + pc.dst + i] = my_spos[pc.src + i]; cev[k0 + pc.dst + i] = my_sev[pc.src + i]; }
+				if (pc.from_span) { npos[k0 + pc.dst + i] = s_span_pos[pc.src + i]; nev[k0 + pc.dst + i] = s_span_ev[pc.src + i]; }
+				else { npos[k0 + pc.dst + i] = my_spos[pc.src + i]; nev[k0 + pc.dst + i] = my_sev[pc.src + i]; }
 			}
 		}
 		__syncthreads();
 		if (tid == 0) {
 			b.ch_len[cx] = s_newlen;
-			if (s_newtail & 0x10000u) cev[s_newlen] = (uint16_t)(s_newtail & 0x7FFu);
+			if (moved) { b.ch_off[cx] = s_newoff; b.ch_cap[cx] = s_newcap; }
+			if (s_newtail & 0x10000u) nev[s_newlen] = (uint16_t)(s_newtail & 0x7FFu);
 		}
 		/* ---- 4. dense checkpoints: this context's value wherever its trajectory changed */
 		for (uint32_t sg = 0; sg < s_nseg; sg++) {

@@ -153,6 +153,7 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
 /* Test hook: raw copy of one of the incremental engine's base structures (selector in
  * mgl_api.hip); *bytes receives the size even when the buffer is too small. */
 int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes);
+int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value);
 /* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the
  * step's own stream (accept decision). */
 uint32_t mgl_rng_draw_at(uint64_t seed, uint64_t step, uint32_t j, uint32_t n);

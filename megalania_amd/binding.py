@@ -28,7 +28,7 @@ F_FULLWALK = 2
 HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
     "mgl_sa_set_slab", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
-    "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump",
+    "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump", "mgl_debug_set",
 ]
 HOST_SYMBOLS = [
     "mgl_lzma_state_init", "mgl_lzma_state_free", "mgl_lzma_encode_packet", "mgl_lzma_encode_header",
@@ -101,6 +101,7 @@ def hip_lib():
                                      C.POINTER(C.c_size_t)]
         L.mgl_neighbours.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.mgl_debug_dump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mgl_debug_set.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.mgl_rng_draw_at.restype = C.c_uint32
         L.mgl_rng_draw_at.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         _hip = L

@@ -275,11 +275,11 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMalloc(&sa->d_sub_lens, sizeof(uint32_t) * sa->sub_cap));
 
 	/* LDS budget: 4 KiB cost table + per wave {probabilities, 2x272 length prices, journal} */
-	sa->per_wave_bytes = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u);
+	sa->per_wave_bytes = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u);
 	sa->waves_per_block = 4;
 	while (sa->waves_per_block > 1 && 4096u + sa->waves_per_block * sa->per_wave_bytes > 160u * 1024u) sa->waves_per_block--;
 	sa->nbr_lds = 4096u + sa->waves_per_block * sa->per_wave_bytes;
-	sa->walk_lds = 4096u + ckpt_elems * 2u + 544u * 4u;
+	sa->walk_lds = 4096u + ckpt_elems * 2u + MGL_PRICE_WORDS * 4u;
 	HIPCHK(hipFuncSetAttribute((const void*)k_neighbours, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr_lds));
 	HIPCHK(hipFuncSetAttribute((const void*)k_rebuild, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->walk_lds));
 	HIPCHK(hipFuncSetAttribute((const void*)k_topk_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->walk_lds));
@@ -309,8 +309,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&b.ch_off, sizeof(uint32_t) * ckpt_elems));
 		HIPCHK(hipMalloc(&b.ch_len, sizeof(uint32_t) * ckpt_elems));
 		HIPCHK(hipMalloc(&b.ch_cap, sizeof(uint32_t) * ckpt_elems));
-		HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * (size_t)b.pool_cap)); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
-		HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * (size_t)b.pool_cap)); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
+		HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * ((size_t)b.pool_cap + 256))); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
+		HIPCHK(hipMemset(b.ch_pos, 0xFF, sizeof(uint32_t) * ((size_t)b.pool_cap + 256)));
+		HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * ((size_t)b.pool_cap + 256))); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
+		HIPCHK(hipMemset(b.ch_ev, 0, sizeof(uint16_t) * ((size_t)b.pool_cap + 256)));
 		HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
 		if (sa->cfg.flags & MGL_F_PROFILE) {
 			HIPCHK(hipMalloc(&sa->d_prof, sizeof(unsigned long long) * 24));
@@ -335,7 +337,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
 			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
 		}
-		sa->per_wave2 = ckpt_elems * 2u + 544u * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) +
+		sa->per_wave2 = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) +
 		                2u * MGL_CHG_CAP * 2u + ((((L.total + 31u) >> 5) * 4u + 15u) & ~15u);
 		{
 			BigScratch& g = sa->big;
@@ -359,6 +361,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 				if (tot > best_total) { best_total = tot; best_w = w; }
 			}
 			sa->waves_per_block2 = best_w;
+			if (getenv("MGL_WAVES_PER_BLOCK")) sa->waves_per_block2 = (uint32_t)atoi(getenv("MGL_WAVES_PER_BLOCK"));
 		}
 		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
 		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;
@@ -730,4 +733,12 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	if (sz > cap_bytes) return fail(MGL_ERANGE, "mgl_debug_dump: buffer too small");
 	HIPCHK(hipMemcpy(out, src, sz, hipMemcpyDeviceToHost));
 	return MGL_OK;
+}
+
+/* diagnostic knobs (tools/): key 0 = stop the neighbour kernel after phase `value` */
+extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	if (key == 0) { sa->ctx.diag_stop = (uint32_t)value; return MGL_OK; }
+	return fail(MGL_EINVAL, "mgl_debug_set: unknown key");
 }

@@ -20,6 +20,7 @@
 #define MGL_CKPT_SHIFT 10u          /* one prefix checkpoint per 1024 input bytes */
 #define MGL_MAX_DIFFS 64u           /* journal capacity per neighbour */
 #define MGL_MAX_TOPK 32u
+#define MGL_PRICE_WORDS 944u          /* top-K price tables per wavefront (u32): 2x272 lengths, 4x64 slots, 128 tails, 16 align */
 #define MGL_SEQ_MASK ((1ull << 44) - 1ull)
 #define MGL_INVALID_COST (~0ull)
 
@@ -33,6 +34,7 @@ struct DevCtx {
 	uint32_t dict_limit;
 	uint32_t max_scan;
 	uint32_t top_k;
+	uint32_t diag_stop;         /* diagnostic: neighbour kernel returns after phase N (0 = run normally) */
 };
 
 struct CkptHdr {

@@ -142,12 +142,39 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	const uint32_t hdr_lr0 = hdr_rep + g0_0 + l_1, hdr_lr1 = hdr_rep + g0_1 + g1_0;
 	const uint32_t hdr_lr2 = hdr_rep + g0_1 + g1_1 + g2_0, hdr_lr3 = hdr_rep + g0_1 + g1_1 + g2_1;
 
-	/* length price tables for both length coders */
-	for (uint32_t l = 2 + lane; l <= MGL_MAX_MATCH; l += 64) {
-		lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
-		lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
+	/* price tables in LDS, the way LZMA encoders price candidates: lencost[0..271] (match) and
+	 * [272..543] (rep) by length; slotcost[len_ctx][slot] at 544; the reverse-tree tail of every
+	 * distance below 128 at 800; the four align bits at 928 (lzma_packet_encoder.c:42-104).
+	 * Lengths >= 18 (the 8-bit high tree) are priced only when a match that long shows up. */
+	uint32_t* slotcost = lencost + 544;
+	uint32_t* disttail = lencost + 800;
+	uint32_t* aligncost = lencost + 928;
+	if (lane < 32) {
+		const uint32_t l = 2 + (lane & 15u);
+		const uint32_t base = lane < 16 ? MGL_OFF_LEN : MGL_OFF_REP_LEN;
+		lencost[(lane < 16 ? 0 : 272) + l - 2] = length_cost(probs, T, base, l, pos_state);
 	}
+	for (uint32_t e = lane; e < 256; e += 64) slotcost[e] = tree_cost(probs, T, MGL_OFF_DIST + (e & ~63u), e & 63u, 6);
+	for (uint32_t d = 4 + lane; d < 128; d += 64) {
+		const uint32_t nlow = mgl_msb32(d) - 2, low = d & ((1u << nlow) - 1u), high = d >> nlow;
+		disttail[d] = rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_POS + (high << nlow) - (nlow * 2 + high), low, nlow);
+	}
+	if (lane < 16) aligncost[lane] = rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_ALIGN, lane, 4);
+	bool high_ready = false;
 	wave_sync();
+	if (c.diag_stop == 31) return;
+	/* cheapest length price of either coder over the lengths priced so far: lower bounds for pruning */
+	uint32_t minlen_m, minlen_r;
+	{
+		uint32_t a = lane < 16 ? lencost[lane] : 0xFFFFFFFFu, b = lane < 16 ? lencost[272 + lane] : 0xFFFFFFFFu;
+		for (int o = 8; o > 0; o >>= 1) {
+			const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, 64), b2 = (uint32_t)__shfl_xor((int)b, o, 64);
+			a = a2 < a ? a2 : a; b = b2 < b ? b2 : b;
+		}
+		minlen_m = uni(a); minlen_r = uni(b);
+	}
+	const uint32_t hdr_lr_min = hdr_lr0 < hdr_lr1 ? (hdr_lr0 < hdr_lr2 ? (hdr_lr0 < hdr_lr3 ? hdr_lr0 : hdr_lr3) : (hdr_lr2 < hdr_lr3 ? hdr_lr2 : hdr_lr3))
+	                                              : (hdr_lr1 < hdr_lr2 ? (hdr_lr1 < hdr_lr3 ? hdr_lr1 : hdr_lr3) : (hdr_lr2 < hdr_lr3 ? hdr_lr2 : hdr_lr3));
 
 	/* LITERAL and SHORT_REP, packet_enumerator.c:60-66 */
 	{
@@ -170,6 +197,7 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 		topk_offer(t, cand, lane);
 	}
 
+	if (c.diag_stop == 32) return;
 	/* substring_enumerator.c:85-105: nothing at the first and the last byte */
 	if (pos == 0 || pos >= c.n - 1) return;
 	const uint32_t bigram = ((uint32_t)walk_byte_at(w, pos) << 8) | c.data[pos + 1];
@@ -179,6 +207,7 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	if (c.max_scan && hi - lo > c.max_scan) lo = hi - c.max_scan;
 	const uint32_t maxlen = (c.n - pos) < MGL_MAX_MATCH ? (c.n - pos) : MGL_MAX_MATCH;
 	const uint32_t inc_type = mgl_pk_type(incumbent), inc_len = mgl_pk_len(incumbent), inc_dist = mgl_pk_dist(incumbent);
+	if (c.diag_stop == 33) { t.count += (hi - lo) & 1u; return; }
 
 	for (uint32_t hb = lo; hb < hi; hb += 64) {
 		const uint32_t idx = hb + lane;
@@ -188,49 +217,84 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 		if (have) {
 			q = c.bucket_pos[idx];
 			d = pos - q - 1;
-			/* match extension, substring_enumerator.c:99-103 */
+			/* match extension, substring_enumerator.c:99-103, eight bytes per step (the input is
+			 * zero-padded past its end; global memory takes unaligned 8-byte loads) */
 			L = 2;
-			while (L < maxlen && c.data[pos + L] == c.data[q + L]) L++;
+			while (L < maxlen) {
+				uint64_t x, y;
+				__builtin_memcpy(&x, c.data + pos + L, 8);
+				__builtin_memcpy(&y, c.data + q + L, 8);
+				const uint64_t df = x ^ y;
+				if (df) { L += ((uint32_t)__ffsll((long long)df) - 1u) >> 3; break; }
+				L += 8;
+			}
+			if (L > maxlen) L = maxlen;
 			repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
 			          (w.st.dists[3] == d ? 8u : 0u);
-			/* distance price per length context, lzma_packet_encoder.c:71-104 */
-			uint32_t slot = d, nlow = 0, low = 0, high = 0;
+			/* distance price per length context from the tables */
+			uint32_t slot = d;
 			if (d >= 4) {
-				nlow = mgl_msb32(d) - 2; low = d & ((1u << nlow) - 1u); high = d >> nlow;
-				slot = nlow * 2 + high;
-				if (slot < 14) tail = rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_POS + (high << nlow) - slot, low, nlow);
-				else tail = ((nlow - 4) << 11) + rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_ALIGN, low & 15u, 4);
+				const uint32_t nlow = mgl_msb32(d) - 2;
+				slot = nlow * 2 + (d >> nlow);
+				tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
 			}
-			s0 = tree_cost(probs, T, MGL_OFF_DIST, slot, 6);
-			if (L > 2) s1 = tree_cost(probs, T, MGL_OFF_DIST + 64, slot, 6);
-			if (L > 3) s2 = tree_cost(probs, T, MGL_OFF_DIST + 128, slot, 6);
-			if (L > 4) s3 = tree_cost(probs, T, MGL_OFF_DIST + 192, slot, 6);
+			s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
 		}
-		uint32_t len = 2, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
+		if (!high_ready && __ballot(have && L >= 18)) {
+			for (uint32_t l = 18 + lane; l <= MGL_MAX_MATCH; l += 64) {
+				lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
+				lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
+			}
+			high_ready = true;
+			wave_sync();
+			uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
+			for (uint32_t l = 16 + lane; l < 272; l += 64) { a = lencost[l] < a ? lencost[l] : a; b = lencost[272 + l] < b ? lencost[272 + l] : b; }
+			for (int o = 32; o > 0; o >>= 1) {
+				const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, 64), b2 = (uint32_t)__shfl_xor((int)b, o, 64);
+				a = a2 < a ? a2 : a; b = b2 < b ? b2 : b;
+			}
+			minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
+		}
+		if (c.diag_stop == 34) { t.key ^= (uint64_t)(s0 + s1 + s2 + s3 + tail + L); continue; }
+		/* Candidates of a hit: for every length 2..L the MATCH and a LONG_REP per rep slot that holds
+		 * this distance (packet_enumerator.c:48-54).  The selection is order-independent, so each lane
+		 * walks its hit from the longest length down (the cheapest per byte first, which tightens the
+		 * threshold at once) and stops as soon as even a lower bound of the price cannot beat the
+		 * current K-th best any more.  The exact perp/len division is only done for candidates that
+		 * pass the multiply test. */
+		uint32_t len = L, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
+		const uint32_t smin = s0 < s1 ? (s0 < s2 ? (s0 < s3 ? s0 : s3) : (s2 < s3 ? s2 : s3)) : (s1 < s2 ? (s1 < s3 ? s1 : s3) : (s2 < s3 ? s2 : s3));
+		const uint32_t lb_m = hdr_match + minlen_m + smin + tail;
+		const uint32_t lb_r = hdr_lr_min + minlen_r;
+		const uint32_t lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
 		while (__ballot(have)) {
-			uint64_t thr = topk_threshold(t);
+			const uint64_t thr = topk_threshold(t);
+			/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
+			const uint64_t lim = thr == MGL_INVALID_COST ? ~0ull : (thr >> 44) + 1ull;
 			uint64_t cand = MGL_INVALID_COST;
 			while (have) {
+				if ((uint64_t)lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
 				uint32_t perp, ctype, cdist;
 				if (kind == 0) {
-					uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
+					const uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
 					perp = hdr_match + lencost[len - 2] + sc + tail;
 					ctype = MGL_MATCH; cdist = d;
 				} else {
-					uint32_t i = kind - 1;
-					uint32_t h = i == 0 ? hdr_lr0 : i == 1 ? hdr_lr1 : i == 2 ? hdr_lr2 : hdr_lr3;
-					perp = h + lencost[272 + len - 2];
+					const uint32_t i = kind - 1;
+					perp = (i == 0 ? hdr_lr0 : i == 1 ? hdr_lr1 : i == 2 ? hdr_lr2 : hdr_lr3) + lencost[272 + len - 2];
 					ctype = MGL_LONG_REP; cdist = i;
 				}
-				uint64_t key = topk_make_key(perp / len, ((uint64_t)(q + 1) << 12) | ((uint64_t)len << 3) | kind);
-				bool skip = ctype == inc_type && len == inc_len && cdist == inc_dist; /* top_k_packet_finder.c:99-101 */
-				/* next candidate of this hit: packet_enumerator.c:48-54 order */
+				const uint32_t clen = len, ckind = kind;
+				/* next candidate of this hit */
 				uint32_t nk = kind + 1;
 				while (nk <= 4 && !((repmask >> (nk - 1)) & 1u)) nk++;
-				if (nk <= 4) kind = nk; else { kind = 0; len++; if (len > L) have = false; }
-				if (!skip && key < thr) { cand = key; break; }
+				if (nk <= 4) kind = nk; else { kind = 0; len--; if (len < 2) have = false; }
+				if ((uint64_t)perp >= lim * clen || c.diag_stop == 36) continue;
+				if (ctype == inc_type && clen == inc_len && cdist == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
+				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(q + 1) << 12) | ((uint64_t)clen << 3) | ckind);
+				if (key < thr) { cand = key; break; }
 			}
-			topk_offer(t, cand, lane);
+			if (c.diag_stop != 35) topk_offer(t, cand, lane);
 		}
 	}
 }
@@ -438,7 +502,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 	uint16_t* probs = (uint16_t*)mine;
 	uint32_t* lencost = (uint32_t*)(mine + (size_t)b.ckpt_elems * 2);
 	Journal jn;
-	jn.old = (mgl_pk*)(lencost + 544);
+	jn.old = (mgl_pk*)(lencost + MGL_PRICE_WORDS);
 	jn.neu = jn.old + MGL_MAX_DIFFS;
 	jn.pos = (uint32_t*)(jn.neu + MGL_MAX_DIFFS);
 	jn.count = 0; jn.overflow = false;

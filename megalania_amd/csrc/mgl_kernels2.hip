@@ -227,6 +227,7 @@ struct Changes {
 	uint32_t n_ins, n_rem; /* uniform */
 	int64_t direct;        /* (inserted - removed) direct-bit cost, uniform */
 	unsigned long long* dbg; /* diagnostic counters (MGL_F_PROFILE), else nullptr */
+	uint32_t diag;
 	bool overflow;
 };
 
@@ -245,6 +246,30 @@ __device__ __forceinline__ void changes_add(Changes& ch, const mgl_plan& pl, uin
 	n += pl.nev;
 	const int64_t d = (int64_t)((uint64_t)pl.ndirect << 11);
 	ch.direct += INS ? d : -d;
+}
+
+/* first index >= start (and < n) whose key, masked, equals cx; n if none.  Eight 16-bit keys
+ * per read (the lists are 16-byte aligned). */
+__device__ __forceinline__ uint32_t next_with_ctx(const uint16_t* keys, uint32_t start, uint32_t n, uint32_t cx, uint32_t mask)
+{
+	uint32_t base = start & ~7u;
+	while (base < n) {
+		const uint4 q = *reinterpret_cast<const uint4*>(keys + base);
+		const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+		uint32_t hit = 0;
+#pragma unroll
+		for (uint32_t e = 0; e < 8; e++) {
+			const uint32_t key = (w[e >> 1] >> ((e & 1u) * 16u)) & mask;
+			hit |= (key == cx ? 1u : 0u) << e;
+		}
+		if (base < start) hit &= ~0u << (start - base);
+		if (hit) {
+			const uint32_t idx = base + (uint32_t)__ffs((int)hit) - 1u;
+			return idx < n ? idx : n;
+		}
+		base += 8;
+	}
+	return n;
 }
 
 /* Price the change lists against the base chains.  Every distinct touched context is
@@ -288,12 +313,12 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 	}
 	wave_sync();
 	int64_t delta = 0;
+	if (ch.diag == 41) return (int64_t)nu;
 	for (uint32_t base = 0; base < nu; base += 64) {
 		if (base + lane >= nu) continue;
 		const uint32_t cx = ch.uctx[base + lane];
-		uint32_t ii = 0, ri = 0;
-		while (ii < ch.n_ins && (ch.ins_key[ii] & 0x7FFFu) != cx) ii++;
-		while (ri < ch.n_rem && ch.rem_key[ri] != cx) ri++;
+		uint32_t ii = next_with_ctx(ch.ins_key, 0, ch.n_ins, cx, 0x7FFFu);
+		uint32_t ri = next_with_ctx(ch.rem_key, 0, ch.n_rem, cx, 0xFFFFu);
 		const uint32_t ipos0 = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
 		const uint32_t rpos0 = ri < ch.n_rem ? ch.rem_pos[ri] : MGL_POS_INF;
 		const uint32_t x0 = ipos0 < rpos0 ? ipos0 : rpos0;
@@ -301,8 +326,30 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 		const uint16_t* cev = b.ch_ev + b.ch_off[cx];
 		const uint32_t clen = b.ch_len[cx];
 		uint32_t k = chain_lower_bound(cpos, clen, x0);
-		uint32_t p = cev[k] & 0x7FFu;
+		/* eight chain entries (positions + events) per round trip, kept in registers */
+		uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa, c_ev = c_pa;
+		uint32_t c_base = 0xFFFFFFFFu;
+		auto chunk = [&](uint32_t kk) {
+			if ((kk & ~7u) != c_base) {
+				c_base = kk & ~7u; /* chains start 32-byte aligned; the pool is over-allocated past its end */
+				c_pa = *reinterpret_cast<const uint4*>(cpos + c_base);
+				c_pb = *reinterpret_cast<const uint4*>(cpos + c_base + 4);
+				c_ev = *reinterpret_cast<const uint4*>(cev + c_base);
+			}
+		};
+		auto pos_at = [&](uint32_t kk) -> uint32_t {
+			const uint32_t e = kk & 7u;
+			return e == 0 ? c_pa.x : e == 1 ? c_pa.y : e == 2 ? c_pa.z : e == 3 ? c_pa.w : e == 4 ? c_pb.x : e == 5 ? c_pb.y : e == 6 ? c_pb.z : c_pb.w;
+		};
+		auto ev_at = [&](uint32_t kk) -> uint32_t {
+			const uint32_t e = kk & 7u;
+			const uint32_t wd = e < 2 ? c_ev.x : e < 4 ? c_ev.y : e < 6 ? c_ev.z : c_ev.w;
+			return (wd >> ((e & 1u) * 16u)) & 0xFFFFu;
+		};
+		chunk(k);
+		uint32_t p = ev_at(k) & 0x7FFu;
 		bool at_limit = false, ended = false;
+		if (ch.diag == 42) { delta += p; continue; }
 		uint32_t iters = 0;
 		/* ---- part 1: while this context still has changes ahead (or a limit applies):
 		 * merge base entries and inserted events by position */
@@ -310,20 +357,20 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 			const bool pending = ii < ch.n_ins || ri < ch.n_rem;
 			if (!pending && limit == MGL_POS_INF) break; /* -> part 2 */
 			iters++;
-			const uint32_t bpos = cpos[k];
+			chunk(k);
+			const uint32_t bpos = pos_at(k);
 			const uint32_t ipos = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
 			if (ipos < bpos) {
 				if (ipos >= limit) { at_limit = true; ended = true; break; }
 				const uint32_t bit = ch.ins_key[ii] >> 15;
 				delta += T[bit ? 2048u - p : p];
 				p = mgl_prob_update(p, bit);
-				ii++;
-				while (ii < ch.n_ins && (ch.ins_key[ii] & 0x7FFFu) != cx) ii++;
+				ii = next_with_ctx(ch.ins_key, ii + 1, ch.n_ins, cx, 0x7FFFu);
 				continue;
 			}
 			if (bpos == MGL_POS_INF) { ended = true; break; }          /* chain exhausted */
 			if (bpos >= limit) { at_limit = true; ended = true; break; }
-			const uint32_t ev = cev[k];
+			const uint32_t ev = ev_at(k);
 			const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
 			if (p == bp) {
 				if (!pending) { ended = true; break; }   /* re-coupled, nothing ahead (limit mode) */
@@ -334,43 +381,54 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 				if (nxt > bpos) {
 					if (nxt >= limit) { ended = true; break; } /* the base value holds at the limit */
 					k += chain_lower_bound(cpos + k, clen - k, nxt);
-					p = cev[k] & 0x7FFu;
+					chunk(k);
+					p = ev_at(k) & 0x7FFu;
 					continue;
 				}
 			}
 			delta -= T[bb ? 2048u - bp : bp];
 			if (ri < ch.n_rem && ch.rem_pos[ri] == bpos) {
-				ri++;
-				while (ri < ch.n_rem && ch.rem_key[ri] != cx) ri++;
+				ri = next_with_ctx(ch.rem_key, ri + 1, ch.n_rem, cx, 0xFFFFu);
 			} else {
 				delta += T[bb ? 2048u - p : p];
 				p = mgl_prob_update(p, bb);
 			}
 			k++;
 		}
+		if (ch.diag == 43) { delta += p; continue; }
 		/* ---- part 2: no change ahead: follow the base chain until the probability re-joins
-		 * the base trajectory.  Only (bit, base probability) is needed: 8 entries per 16-byte
-		 * load, so a cache line is fetched once, not once per entry. */
-		while (!ended) {
-			const uint32_t start = k & 7u, k8 = k - start;
-			const uint4 q = *reinterpret_cast<const uint4*>(cev + k8); /* chains start 16-byte aligned */
-			const uint32_t w0 = q.x, w1 = q.y, w2 = q.z, w3 = q.w;
+		 * the base trajectory.  Only (bit, base probability) is needed: 16 entries per round
+		 * trip (two 16-byte loads), the next 16 already in flight while these are processed. */
+		if (!ended) {
+			uint32_t kb = k & ~15u;
+			uint4 a0 = *reinterpret_cast<const uint4*>(cev + kb);
+			uint4 a1 = *reinterpret_cast<const uint4*>(cev + kb + 8);
+			while (!ended) {
+				/* may read up to 64 bytes past the sentinel: the pool is over-allocated for that */
+				const uint4 n0 = *reinterpret_cast<const uint4*>(cev + kb + 16);
+				const uint4 n1 = *reinterpret_cast<const uint4*>(cev + kb + 24);
 #pragma unroll
-			for (uint32_t e = 0; e < 8; e++) {
-				if (ended || e < start) continue;
-				if (k8 + e >= clen) { ended = true; continue; }            /* chain exhausted */
-				const uint32_t wd = e < 2 ? w0 : e < 4 ? w1 : e < 6 ? w2 : w3;
-				const uint32_t ev = (wd >> ((e & 1u) * 16u)) & 0xFFFFu;
-				const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
-				if (p == bp) { ended = true; continue; }                   /* re-coupled */
-				delta += (int64_t)T[bb ? 2048u - p : p] - (int64_t)T[bb ? 2048u - bp : bp];
-				p = mgl_prob_update(p, bb);
-				iters++;
+				for (uint32_t e = 0; e < 16; e++) {
+					const uint32_t idx = kb + e;
+					if (ended || idx < k) continue;
+					if (idx >= clen) { ended = true; continue; }               /* chain exhausted */
+					const uint4 q = e < 8 ? a0 : a1;
+					const uint32_t h = e & 7u;
+					const uint32_t wd = h < 2 ? q.x : h < 4 ? q.y : h < 6 ? q.z : q.w;
+					const uint32_t ev = (wd >> ((h & 1u) * 16u)) & 0xFFFFu;
+					const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+					if (p == bp) { ended = true; continue; }                   /* re-coupled */
+					delta += (int64_t)T[bb ? 2048u - p : p] - (int64_t)T[bb ? 2048u - bp : bp];
+					p = mgl_prob_update(p, bb);
+					iters++;
+				}
+				a0 = n0; a1 = n1; kb += 16;
 			}
-			k = k8 + 8;
+			k = kb;
 		}
 		if (ch.dbg) atomicMax(&ch.dbg[21], (unsigned long long)iters);
 		if (overlay && (at_limit || (limit != MGL_POS_INF && cpos[k] == MGL_POS_INF))) overlay[cx] = (uint16_t)p;
+		(void)c_base;
 	}
 	/* signed wave sum */
 	uint64_t u = (uint64_t)delta;
@@ -493,7 +551,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 	uint16_t* probs = (uint16_t*)mine;
 	uint32_t* lencost = (uint32_t*)(mine + (size_t)b.ck_elems * 2);
 	Journal jn;
-	jn.old = (mgl_pk*)(lencost + 544);
+	jn.old = (mgl_pk*)(lencost + MGL_PRICE_WORDS);
 	jn.neu = jn.old + MGL_MAX_DIFFS;
 	jn.pos = (uint32_t*)(jn.neu + MGL_MAX_DIFFS);
 	jn.count = 0; jn.overflow = false;
@@ -544,6 +602,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 	Prof prof;
 	prof_start(prof, prof_acc);
 	ch.dbg = prof_acc;
+	ch.diag = c.diag_stop;
 	const uint32_t pos = target;
 	mgl_wstate nb = uni_state(base_state_at(b, pos)); /* neighbour's walk state */
 	mgl_wstate bs = nb;                               /* base's walk state */
@@ -556,6 +615,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 	mgl_pk m_first = first, m_second = 0;
 	bool second_set = false, mutated = false;
 	prof_mark(prof, 0, lane); /* state at target */
+	if (c.diag_stop == 1) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = first; } return; }
 	if (pos + 1 < c.n && (nbr_draw(rng) % 2u) == 0) {
 		const mgl_pk second = uni64(b.slab[pos + 1]);
 		const uint32_t ft = mgl_pk_type(first), flen = mgl_pk_len(first);
@@ -578,6 +638,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 	if (!mutated) {
 		model_at(c, b, ch, probs, T, pos, lane, &too_many);
 		prof_mark(prof, 1, lane); /* model at target */
+		if (c.diag_stop == 2) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = probs[lane]; } return; }
 		walk_from_state(tw, nb);
 		walk_window(tw, c, b.slab, lane);
 		mgl_pk picked;
@@ -590,6 +651,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 		prof_mark(prof, 2, lane); /* top-K */
 	}
 
+	if (c.diag_stop == 3 || (c.diag_stop >= 31 && c.diag_stop <= 36)) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = (uint32_t)m_first; } return; }
 	/* ---- two-pointer walk over neighbour packets (nb) and base packets (bs) */
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
@@ -697,6 +759,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 	}
 
 	prof_mark(prof, 3, lane); /* window walk */
+	if (c.diag_stop == 4) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = ch.n_ins + ch.n_rem; } return; }
 	int64_t delta = 0;
 	if (!ch.overflow && !jn.overflow && !too_many) delta = chain_sim(b, ch, T, MGL_POS_INF, nullptr, lane, &too_many);
 	prof_mark(prof, 4, lane); /* chain re-simulation */

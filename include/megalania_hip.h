@@ -94,6 +94,7 @@ typedef struct {
 	uint64_t neighbour_launches;
 	uint64_t full_rebuilds;       /* accepted steps whose base update fell back to a full rebuild */
 	uint64_t fallback_neighbours; /* neighbours costed by the full-walk kernel instead of incrementally */
+	uint64_t second_pass_neighbours; /* neighbours redone incrementally with their lists in global memory */
 } mgl_sa_stats;
 
 typedef struct {

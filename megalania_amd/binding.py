@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("improved", C.c_uint64), ("current_cost", C.c_uint64), ("best_cost", C.c_uint64),
                 ("packets", C.c_uint64), ("packets_evaluated", C.c_uint64), ("gpu_ms_total", C.c_double),
                 ("gpu_ms_neighbours", C.c_double), ("gpu_ms_rebuild", C.c_double), ("neighbour_launches", C.c_uint64),
-                ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64)]
+                ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64), ("second_pass_neighbours", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -83,6 +83,7 @@ struct mgl_sa {
 	size_t b2_bytes;
 	BigScratch big;
 	uint32_t* d_todo2;
+	uint32_t* d_counts;     /* [0] first-pass overflow count, [1] second-pass overflow count, [2] spill slots used */
 	ApplyBuf ab;
 	uint32_t apply_blocks;
 	bool incremental_apply;
@@ -139,7 +140,7 @@ static int launch_apply(mgl_sa* sa)
 	hipLaunchKernelGGL(k_apply_walk, dim3(1), dim3(64), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, sa->ab);
 	hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
 	                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
-	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(256), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
+	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
 	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl);
 	HIPCHK(hipGetLastError());
@@ -156,22 +157,21 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 		HIPCHK(hipGetLastError());
 		return MGL_OK;
 	}
-	HIPCHK(hipMemsetAsync(sa->d_todo, 0, sizeof(uint32_t), sa->stream));
-	HIPCHK(hipMemsetAsync(sa->d_todo2, 0, sizeof(uint32_t), sa->stream));
+	HIPCHK(hipMemsetAsync(sa->d_counts, 0, 4 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	hipLaunchKernelGGL(k_neighbours2<false>, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
-	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo + 1, sa->d_todo,
+	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
 	                   sa->d_prof, sa->big);
 	/* the few whose change lists overflowed LDS: same kernel, lists in global scratch */
 	const uint32_t bigblocks = (MGL_BIG_SLOTS + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	hipLaunchKernelGGL(k_neighbours2<true>, dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
-	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2 + 1, sa->d_todo2,
+	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
 	                   (unsigned long long*)nullptr, sa->big);
 	/* and whatever overflowed even that: exact full walk from byte 0 */
 	const uint32_t blocks = (MGL_BIG_SLOTS + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
-	                   (const uint32_t*)(sa->d_todo2 + 1), (const uint32_t*)sa->d_todo2);
+	                   (const uint32_t*)sa->d_todo2, (const uint32_t*)(sa->d_counts + 1));
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -207,7 +207,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->b2.ch_off); dfree(sa->b2.ch_len); dfree(sa->b2.ch_cap); dfree(sa->b2.ch_pos); dfree(sa->b2.ch_ev);
 	dfree(sa->b2.pool_top); dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->d_todo2);
+	dfree(sa->d_todo2); dfree(sa->d_counts);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
@@ -325,7 +325,9 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		{
 			ApplyBuf& ab = sa->ab;
 			memset(&ab, 0, sizeof ab);
-			sa->apply_blocks = 32;
+			/* one workgroup per touched context where memory allows (scratch = one chain region each) */
+			sa->apply_blocks = 128;
+			while (sa->apply_blocks > 8 && (size_t)sa->apply_blocks * (n + 64) * 6 > ((size_t)4 << 30)) sa->apply_blocks /= 2;
 			ab.scratch_stride = (uint32_t)n + 64u;
 			HIPCHK(hipMalloc(&ab.hdr, sizeof(uint32_t) * 16));
 			HIPCHK(hipMemset(ab.hdr, 0, sizeof(uint32_t) * 16));
@@ -337,8 +339,13 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
 			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
 		}
-		sa->per_wave2 = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u + MGL_MAX_DIFFS * (8u + 8u + 4u) + MGL_CHG_CAP * (4u + 4u + 2u + 2u) +
-		                2u * MGL_CHG_CAP * 2u + ((((L.total + 31u) >> 5) * 4u + 15u) & ~15u);
+		{
+			/* journal + context bitmap + max(model + price tables, change lists + context list) */
+			const uint32_t fixed = MGL_MAX_DIFFS * (8u + 8u + 4u) + (((((L.total + 31u) >> 5) + 3u) & ~3u) * 4u) ;
+			const uint32_t model = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u;
+			const uint32_t lists = MGL_CHG_CAP * (4u + 4u + 2u + 2u) + 2u * MGL_CHG_CAP * 2u;
+			sa->per_wave2 = (fixed + (model > lists ? model : lists) + 15u) & ~15u;
+		}
 		{
 			BigScratch& g = sa->big;
 			memset(&g, 0, sizeof g);
@@ -360,12 +367,16 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 				const uint32_t tot = (160u * 1024u / bytes) * w;
 				if (tot > best_total) { best_total = tot; best_w = w; }
 			}
-			sa->waves_per_block2 = best_w;
+			(void)best_w; /* measured: one wavefront per workgroup wins although it packs fewer waves (LDS is
+			               * released per workgroup, and neighbour run times have a long tail) */
+			sa->waves_per_block2 = 1;
 			if (getenv("MGL_WAVES_PER_BLOCK")) sa->waves_per_block2 = (uint32_t)atoi(getenv("MGL_WAVES_PER_BLOCK"));
 		}
 		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
 		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;
-		sa->big.todo_in = sa->d_todo + 1; sa->big.todo_in_count = sa->d_todo;
+		HIPCHK(hipMalloc(&sa->d_counts, sizeof(uint32_t) * 4));
+		HIPCHK(hipMemset(sa->d_counts, 0, sizeof(uint32_t) * 4));
+		sa->big.todo_in = sa->d_todo; sa->big.todo_in_count = sa->d_counts; sa->big.spill_ctr = sa->d_counts + 2;
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
@@ -524,6 +535,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		stats->neighbour_launches = timed_steps;
 		stats->full_rebuilds = after.full_rebuilds - before.full_rebuilds;
 		stats->fallback_neighbours = after.fallback_nbrs - before.fallback_nbrs;
+		stats->second_pass_neighbours = after.big_nbrs - before.big_nbrs;
 	}
 	if (after.error_flags) {
 		char buf[96];
@@ -726,7 +738,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * 24 : 0; break;
-	case 10: src = sa->d_todo; sz = sizeof(uint32_t); break;
+	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
 	}
 	*bytes = sz;

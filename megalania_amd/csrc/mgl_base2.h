@@ -26,7 +26,10 @@
 #define MGL_POS_INF 0xFFFFFFFFu
 #define MGL_CHG_CAP 256u   /* inserted / removed events per neighbour kept in LDS */
 #define MGL_BIG_CAP 8192u   /* the same, per flagged neighbour, in the global scratch of the second pass */
-#define MGL_BIG_SLOTS 128u
+#define MGL_BIG_SLOTS 512u
+#ifndef MGL_NBR_WAVES_PER_SIMD
+#define MGL_NBR_WAVES_PER_SIMD 2 /* register budget of the neighbour kernel: 2 -> 256 VGPRs, 3 -> 168 */
+#endif
 
 struct Base2 {
 	mgl_pk* slab;

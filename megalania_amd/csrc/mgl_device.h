@@ -63,6 +63,7 @@ struct Control {
 	uint32_t apply_failed; /* the incremental accept did not fit: rebuild from the slab */
 	uint32_t full_rebuilds;  /* accepts that went through k_build */
 	uint64_t fallback_nbrs;  /* neighbours costed by the full-walk kernel (did not fit the LDS lists) */
+	uint64_t big_nbrs;       /* neighbours redone by the second (global-scratch) pass */
 	uint32_t final_ctx_state;
 	uint32_t final_dists[4];
 	uint32_t error_flags;

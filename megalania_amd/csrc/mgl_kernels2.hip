@@ -526,9 +526,10 @@ struct BigScratch {
 	uint16_t* ins_key; uint32_t* ins_pos; uint16_t* rem_key; uint32_t* rem_pos; uint16_t* uctx;
 	uint32_t cap, uctx_cap, slots;
 	const uint32_t* todo_in; const uint32_t* todo_in_count;
+	uint32_t* spill_ctr; /* slots handed out to first-pass wavefronts that had to spill their lists */
 };
 template <bool BIG>
-__global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
+__global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
                                                      BigScratch big)
@@ -547,23 +548,29 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 		j = uni(big.todo_in[slot]);
 	}
 	if (j >= K) return;
+	/* LDS per wavefront: [journal | context bitmap | union].  The union holds EITHER the model +
+	 * top-K price tables (while the mutation is chosen) OR the change lists (afterwards): the
+	 * lists only start to fill once the mutated packet is known.  A repair that needs another
+	 * top-K pick while the lists are live is handed to the BIG pass, whose lists are in global
+	 * memory.  This keeps 11 instead of 8 wavefronts per CU. */
 	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
-	uint16_t* probs = (uint16_t*)mine;
-	uint32_t* lencost = (uint32_t*)(mine + (size_t)b.ck_elems * 2);
 	Journal jn;
-	jn.old = (mgl_pk*)(lencost + MGL_PRICE_WORDS);
+	jn.old = (mgl_pk*)mine;
 	jn.neu = jn.old + MGL_MAX_DIFFS;
 	jn.pos = (uint32_t*)(jn.neu + MGL_MAX_DIFFS);
 	jn.count = 0; jn.overflow = false;
 	Changes ch;
-	ch.ins_pos = jn.pos + MGL_MAX_DIFFS;
+	ch.nbitwords = (c.L.total + 31u) >> 5;
+	ch.ctxbits = jn.pos + MGL_MAX_DIFFS;
+	unsigned char* uni_base = (unsigned char*)(ch.ctxbits + ((ch.nbitwords + 3u) & ~3u));
+	uint16_t* probs = (uint16_t*)uni_base;
+	uint32_t* lencost = (uint32_t*)(uni_base + (size_t)b.ck_elems * 2);
+	ch.ins_pos = (uint32_t*)uni_base;
 	ch.rem_pos = ch.ins_pos + MGL_CHG_CAP;
 	ch.ins_key = (uint16_t*)(ch.rem_pos + MGL_CHG_CAP);
 	ch.rem_key = ch.ins_key + MGL_CHG_CAP;
 	ch.uctx = ch.rem_key + MGL_CHG_CAP;
-	ch.ctxbits = (uint32_t*)(ch.uctx + 2 * MGL_CHG_CAP);
 	ch.cap = MGL_CHG_CAP; ch.uctx_cap = 2 * MGL_CHG_CAP;
-	ch.nbitwords = (c.L.total + 31u) >> 5;
 	if (BIG) {
 		if (slot >= big.slots) { /* more flagged neighbours than scratch slots: full walk */
 			if (lane == 0) { const uint32_t s2 = atomicAdd(todo_count, 1u); todo[s2] = j; }
@@ -576,6 +583,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 	}
 	ch.n_ins = ch.n_rem = 0; ch.direct = 0; ch.overflow = false;
 	bool too_many = false;
+	bool spilled = BIG;
 
 	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
 	NbrRng rng; rng.key = mgl_rng_key(seed, gstep, j); rng.n = 0;
@@ -703,6 +711,24 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 					for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, tw, idx, len, lane); }
 					pk = mgl_pack(MGL_LONG_REP, idx, len);
 					if (!ok) {
+						if (!BIG && !spilled) {
+							/* the model is about to overwrite the live lists (they share LDS): move the
+							 * lists to a global scratch slot and carry on from there */
+							uint32_t sl = 0;
+							if (lane == 0) sl = atomicAdd(big.spill_ctr, 1u);
+							sl = uni(sl);
+							if (sl >= big.slots) { ch.overflow = true; break; }
+							uint16_t* gik = big.ins_key + (size_t)sl * big.cap; uint32_t* gip = big.ins_pos + (size_t)sl * big.cap;
+							uint16_t* grk = big.rem_key + (size_t)sl * big.cap; uint32_t* grp = big.rem_pos + (size_t)sl * big.cap;
+							for (uint32_t i = lane; i < ch.n_ins; i += 64) { gik[i] = ch.ins_key[i]; gip[i] = ch.ins_pos[i]; }
+							for (uint32_t i = lane; i < ch.n_rem; i += 64) { grk[i] = ch.rem_key[i]; grp[i] = ch.rem_pos[i]; }
+							__threadfence_block();
+							wave_sync();
+							ch.ins_key = gik; ch.ins_pos = gip; ch.rem_key = grk; ch.rem_pos = grp;
+							ch.uctx = big.uctx + (size_t)sl * big.uctx_cap;
+							ch.cap = big.cap; ch.uctx_cap = big.uctx_cap;
+							spilled = true;
+						}
 						const bool best = (nbr_draw(rng) % 4u) == 0;
 						/* the model at p needs every base packet that starts before p priced in */
 						while (bs.pos < p && !ch.overflow) {
@@ -772,7 +798,7 @@ __global__ void __launch_bounds__(512) k_neighbours2(DevCtx c, Base2 b, Control*
 		if (lane == 0) {
 			const uint32_t slot = atomicAdd(todo_count, 1u);
 			todo[slot] = j;
-			if (BIG) atomicAdd((unsigned long long*)&ctl->fallback_nbrs, 1ull);
+			atomicAdd((unsigned long long*)(BIG ? &ctl->fallback_nbrs : &ctl->big_nbrs), 1ull);
 			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
 		}
 		return;

@@ -21,6 +21,7 @@
 #define MGL_SUB_CAP 1024u     /* per context */
 #define MGL_SPAN_CAP 4096u    /* rewritten chain entries per context */
 #define MGL_PIECE_CAP 160u
+#define MGL_APPLY_THREADS 1024u
 
 struct ApplyBuf {
 	uint32_t* hdr;      /* [0] n_ins [1] n_rem [2] n_tctx [3] first journal position */
@@ -232,7 +233,7 @@ struct Piece {
 	uint32_t from_span;
 };
 
-__global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control* ctl, ApplyBuf ab)
+__global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Control* ctl, ApplyBuf ab)
 {
 	__shared__ uint32_t s_ipos[MGL_SUB_CAP];
 	__shared__ uint16_t s_ibit[MGL_SUB_CAP];
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 	/* checkpoint patch segments: positions (lo, hi] take their value from span[first..last) */
 	__shared__ uint32_t s_seg_lo[MGL_PIECE_CAP], s_seg_hi[MGL_PIECE_CAP], s_seg_first[MGL_PIECE_CAP], s_seg_last[MGL_PIECE_CAP];
 	__shared__ uint16_t s_seg_endp[MGL_PIECE_CAP];
-	__shared__ uint32_t s_wcount[8];
+	__shared__ uint32_t s_wcount[16];
 	__shared__ uint32_t s_ni, s_nr, s_npiece, s_nseg, s_k0, s_newtail, s_oldlen, s_fail, s_newlen, s_newoff, s_newcap;
 	if (!ctl->accepted_flag || ctl->apply_failed) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 		/* ---- 1. this context's inserted / removed events, order preserved */
 		for (int pass = 0; pass < 2; pass++) {
 			const uint32_t m = pass == 0 ? n_ins : n_rem;
-			for (uint32_t base = 0; base < m; base += 256) {
+			for (uint32_t base = 0; base < m; base += MGL_APPLY_THREADS) {
 				const uint32_t e = base + tid;
 				bool hit = false;
 				uint32_t key = 0, pos = 0;
@@ -282,7 +283,8 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 				}
 				__syncthreads();
 				if (tid == 0) {
-					const uint32_t tot = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+					uint32_t tot = 0;
+					for (uint32_t w = 0; w < MGL_APPLY_THREADS / 64; w++) tot += s_wcount[w];
 					if (pass == 0) s_ni += tot; else s_nr += tot;
 				}
 				__syncthreads();
@@ -384,12 +386,12 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 		const bool moved = s_newoff != off;
 		uint32_t* npos = b.ch_pos + s_newoff;
 		uint16_t* nev = b.ch_ev + s_newoff;
-		for (uint32_t i = tid; i < oldlen + 1 - k0; i += 256) { my_spos[i] = cpos[k0 + i]; my_sev[i] = cev[k0 + i]; }
-		if (moved) for (uint32_t i = tid; i < k0; i += 256) { npos[i] = cpos[i]; nev[i] = cev[i]; }
+		for (uint32_t i = tid; i < oldlen + 1 - k0; i += MGL_APPLY_THREADS) { my_spos[i] = cpos[k0 + i]; my_sev[i] = cev[k0 + i]; }
+		if (moved) for (uint32_t i = tid; i < k0; i += MGL_APPLY_THREADS) { npos[i] = cpos[i]; nev[i] = cev[i]; }
 		__syncthreads();
 		for (uint32_t pi = 0; pi < s_npiece; pi++) {
 			const Piece pc = s_piece[pi];
-			for (uint32_t i = tid; i < pc.count; i += 256) {
+			for (uint32_t i = tid; i < pc.count; i += MGL_APPLY_THREADS) {
 				if (pc.from_span) { npos[k0 + pc.dst + i] = s_span_pos[pc.src + i]; nev[k0 + pc.dst + i] = s_span_ev[pc.src + i]; }
 				else { npos[k0 + pc.dst + i] = my_spos[pc.src + i]; nev[k0 + pc.dst + i] = my_sev[pc.src + i]; }
 			}
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(256) k_apply_chains(DevCtx c, Base2 b, Control
 			/* a boundary can lie behind a packet that starts up to 272 bytes before lo */
 			const uint32_t ck_lo = (lo > MGL_MAX_MATCH ? lo - MGL_MAX_MATCH : 0u) >> MGL_CK2_SHIFT;
 			const uint32_t ck_hi = hi == MGL_POS_INF ? b.nck : ((hi >> MGL_CK2_SHIFT) + 1u < b.nck ? (hi >> MGL_CK2_SHIFT) + 1u : b.nck);
-			for (uint32_t ck = ck_lo + tid; ck < ck_hi; ck += 256) {
+			for (uint32_t ck = ck_lo + tid; ck < ck_hi; ck += MGL_APPLY_THREADS) {
 				const uint32_t P = ckpt_boundary(b, ck); /* MGL_POS_INF: behind the last packet = final model */
 				if (P <= lo || P > hi) continue;     /* value there is the old one */
 				/* probability before the first new event of this segment at or after P */

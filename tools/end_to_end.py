@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""End-to-end record for a BASELINE config: run the GPU SA for a fixed number of steps, emit the
+best slab through the C host emitter, verify the stream with liblzma (and xz if present), and run
+the reference CPU path (oracle/_ref, else the oracle) for the same number of *iterations*.
+
+  python tools/end_to_end.py c2 100000 [cpu_iters]
+"""
+import json, lzma, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from megalania_amd import binding, corpus
+import _libs
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+cpu_iters = int(sys.argv[3]) if len(sys.argv) > 3 else steps
+data, desc = corpus.config_input(cfg)
+n = len(data)
+K = {"c1": 1024, "c2": 4096, "c3": 16384, "c5": 4096}[cfg]
+out = dict(config=cfg, input=desc, n=n, neighbours_per_step=K, steps=steps)
+sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=max(n, steps), **({"pb": 2} if cfg == "c5" else {}))
+t0 = time.perf_counter()
+done, trace = 0, []
+while done < steps:
+    chunk = min(10000, steps - done)
+    st = sa.run(chunk)
+    done += chunk
+    trace.append((done, st["best_cost"], round(time.perf_counter() - t0, 2)))
+    print(f"gpu step {done}: best est {18 + st['best_cost'] / 16384:.1f} B, {time.perf_counter() - t0:.1f} s", flush=True)
+gpu_s = time.perf_counter() - t0
+best, best_cost = sa.best()
+stream = binding.emit_stream(data, best, pb=2 if cfg == "c5" else 0)
+assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
+xz_ok = None
+try:
+    r = subprocess.run(["xz", "-dc", "--format=lzma"], input=stream, capture_output=True, timeout=120)
+    xz_ok = r.returncode == 0 and r.stdout == data
+except Exception:
+    pass
+out.update(gpu_seconds=round(gpu_s, 2), gpu_evals_per_s=round(steps * K / gpu_s), gpu_best_perplexity=best_cost,
+           gpu_stream_bytes=len(stream), liblzma_roundtrip=True, xz_roundtrip=xz_ok,
+           xz9e_same_props_bytes=len(lzma.compress(data, format=lzma.FORMAT_ALONE, filters=[
+               {"id": lzma.FILTER_LZMA1, "preset": 9 | lzma.PRESET_EXTREME, "lc": 0, "lp": 0, "pb": 2 if cfg == "c5" else 0}])),
+           xz9e_default_props_bytes=len(lzma.compress(data, format=lzma.FORMAT_ALONE, preset=9 | lzma.PRESET_EXTREME)),
+           gpu_trace=trace)
+sa.close()
+if cpu_iters and cfg != "c5":
+    kind = "reference" if _libs.Ref.available() else "port"
+    eng = _libs.Ref(data) if kind == "reference" else _libs.Oracle(data)
+    (_libs.Ref.lib().ref_srand if kind == "reference" else _libs.Oracle.lib().orc_srand)(1673551)
+    slab, bst = _libs.literal_slab(n), _libs.literal_slab(n)
+    cur = b = 0
+    t0 = time.perf_counter()
+    i = 0
+    while i < cpu_iters:
+        j = min(i + 2000, cpu_iters)
+        r = eng.sa_iters(slab, bst, cur, b, 0, max(n, cpu_iters), i, j)
+        cur, b = r["cur"], r["best"]
+        i = j
+        if i % 20000 == 0:
+            print(f"cpu iter {i}: best est {18 + b / 16384:.1f} B, {time.perf_counter() - t0:.1f} s", flush=True)
+    cpu_s = time.perf_counter() - t0
+    o = _libs.Oracle(data)
+    cstream = o.emit(bst)
+    assert lzma.decompress(cstream, format=lzma.FORMAT_ALONE) == data
+    out.update(cpu_kind=kind, cpu_iters=cpu_iters, cpu_seconds=round(cpu_s, 1), cpu_evals_per_s=round(cpu_iters / cpu_s, 1),
+               cpu_best_perplexity=b, cpu_stream_bytes=len(cstream))
+print(json.dumps(out))

@@ -9,7 +9,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 K = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 full = len(sys.argv) > 5 and sys.argv[5] == "fullwalk"
 data, desc = corpus.config_input(cfg)
-sa = binding.SA(data, neighbours_per_step=K, timing=True, fullwalk=full, **({"pb": 2} if cfg == "c5" else {}))
+sa = binding.SA(data, neighbours_per_step=K, timing=True, fullwalk=full, **({"pb": 2, "max_bucket_scan": 4096} if cfg == "c5" else {}))
 if warm:
     sa.run(warm)
 st = sa.run(steps)

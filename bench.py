@@ -62,6 +62,45 @@ def cpu_baseline(data, seconds):
                        f"{n} B input in {el:.1f} s on 1 thread")
 
 
+def _cpu_worker(args):
+    data, seconds, seed = args
+    import _libs
+    n = len(data)
+    eng = _libs.Ref(data) if _libs.Ref.available() else _libs.Oracle(data)
+    (_libs.Ref.lib().ref_srand if _libs.Ref.available() else _libs.Oracle.lib().orc_srand)(seed)
+    slab, best = _libs.literal_slab(n), _libs.literal_slab(n)
+    cur = bst = 0
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        r = eng.sa_iters(slab, best, cur, bst, 0, n, done, done + 100)
+        cur, bst = r["cur"], r["best"]
+        done += 100
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(data, seconds):
+    """Independent chains, one process per host core (the reference is not re-entrant)."""
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 16)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(data, seconds, 1673551 + i) for i in range(cores)])
+    total = sum(d for d, _ in res)
+    wall = max(t for _, t in res)
+    return dict(value=total / wall, unit="evals/s", cores=cores, kind="reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libmegalania_ref.so")) else "port",
+                sample=f"{total} SA iterations over {cores} independent chains in {wall:.1f} s")
+
+
+def pmc_traffic():
+    """HBM traffic of the dominant kernel from a separate `rocprofv3 --pmc` pass (the guide's
+    recipe: counters in their own run), recorded by tools/collect_pmc.sh into profiles/."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return d.get("bytes_per_launch"), d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,8 +201,13 @@ def main():
                       "gpu_ms_total": st["gpu_ms_total"], "full_rebuilds": st["full_rebuilds"],
                       "fallback_neighbours": st["fallback_neighbours"]},
         }
+        traffic, src = pmc_traffic()
+        if traffic is not None and args.config == "c2":
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = src
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(data, args.cpu_seconds)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(data, min(args.cpu_seconds, 8.0))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

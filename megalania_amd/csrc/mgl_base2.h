@@ -28,7 +28,8 @@
 #define MGL_BIG_CAP 8192u   /* the same, per flagged neighbour, in the global scratch of the second pass */
 #define MGL_BIG_SLOTS 512u
 #ifndef MGL_NBR_WAVES_PER_SIMD
-#define MGL_NBR_WAVES_PER_SIMD 2 /* register budget of the neighbour kernel: 2 -> 256 VGPRs, 3 -> 168 */
+#define MGL_NBR_WAVES_PER_SIMD 2 /* register budget of the neighbour kernel: 2 -> 256 VGPRs, no scratch; 3 -> 168 VGPRs
+                                    but 200 B/lane of scratch (52 MB of spill traffic per launch) for the same speed */
 #endif
 
 struct Base2 {

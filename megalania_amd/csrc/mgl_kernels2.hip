@@ -482,11 +482,9 @@ __device__ __forceinline__ void plan_at(const DevCtx& c, const mgl_wstate& st, u
 	mgl_plan_packet(&c.L, &st, type, dist, len, byte, match_byte, prev_byte, &pl);
 }
 
-/* The adaptive model the neighbour has at position y, in LDS: base model before the first
- * base packet at or after y (dense checkpoint + replay of < 64 bytes of base packets), with
- * the touched contexts overridden by their re-simulated values. */
-__device__ void model_at(const DevCtx& c, const Base2& b, Changes& ch, uint16_t* probs, const uint16_t* T, uint32_t y,
-                         uint32_t lane, bool* too_many)
+/* The base's adaptive model before the first base packet at or after y, into LDS: dense
+ * checkpoint + replay of < 64 bytes of base packets. */
+__device__ void model_load(const DevCtx& c, const Base2& b, uint16_t* probs, const uint16_t* T, uint32_t y, uint32_t lane)
 {
 	const uint32_t ck = y >> MGL_CK2_SHIFT;
 	const uint32_t* src = (const uint32_t*)(b.ck_probs + (size_t)ck * b.ck_elems);
@@ -507,8 +505,6 @@ __device__ void model_at(const DevCtx& c, const Base2& b, Changes& ch, uint16_t*
 		}
 		wave_sync();
 	}
-	if (ch.n_ins + ch.n_rem) chain_sim(b, ch, T, y, probs, lane, too_many);
-	wave_sync();
 }
 
 /* the Walk-based helpers of the full-walk path read the input through Walk's window */
@@ -643,161 +639,210 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 			}
 		}
 	}
-	if (!mutated) {
-		model_at(c, b, ch, probs, T, pos, lane, &too_many);
-		prof_mark(prof, 1, lane); /* model at target */
-		if (c.diag_stop == 2) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = probs[lane]; } return; }
-		walk_from_state(tw, nb);
-		walk_window(tw, c, b.slab, lane);
-		mgl_pk picked;
-		if (!pick_from_top_k(c, tw, probs, T, lencost, first, false, rng, lane, &picked)) {
-			if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
-			return;
-		}
-		m_first = picked;
-		journal_set(jn, pos, first, m_first, lane);
-		prof_mark(prof, 2, lane); /* top-K */
-	}
-
-	if (c.diag_stop == 3 || (c.diag_stop >= 31 && c.diag_stop <= 36)) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = (uint32_t)m_first; } return; }
-	/* ---- two-pointer walk over neighbour packets (nb) and base packets (bs) */
+	/* ---- the rest runs as a small phase machine so that each big piece of code (model load,
+	 * chain re-simulation, top-K) exists exactly once in the kernel: the mutation's top-K pick and
+	 * a repair's top-K pick share one site, and so do the overlay re-simulation (model at a repair
+	 * position) and the final one.  Halves the code size and the register pressure. */
+	enum { P_MODEL, P_SIM, P_TOPK, P_WALK, P_OUT };
+	uint32_t phase = mutated ? P_WALK : P_MODEL;
+	/* pending top-K request */
+	bool pick_is_mutation = !mutated;
+	uint32_t pick_pos = pos;
+	mgl_pk pick_inc = first;
+	bool pick_best = false;
+	/* its result, handed back to the walk */
+	bool have_pick = false;
+	mgl_pk picked_pk = 0, resume_old = 0;
+	/* re-simulation request */
+	uint32_t sim_limit = MGL_POS_INF;
+	bool sim_overlay = false;
+	int64_t delta = 0;
+	bool generate_failed = false;
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
 	bool first_packet = true;
 	uint32_t guard = 0;
-	while (nb.pos < c.n || bs.pos < c.n) {
-		if (ch.overflow || jn.overflow || too_many || ++guard > (BIG ? (1u << 20) : 4096u)) { ch.overflow = true; break; }
-		if (!first_packet && nb.pos == bs.pos && count >= 3) {
-			const bool same_ctx = nb.ctx_state == bs.ctx_state;
-			const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
-			                    nb.dists[3] == bs.dists[3];
-			if (same_ctx && same_d) break; /* the rest of the file is coded identically */
-			if (same_ctx && nb.ctx_state < 7) {
-				/* plain literals up to the next special packet code identically: skip them */
-				uint32_t s = uni(sp_find_next(b, nb.pos));
-				if (s == MGL_POS_INF || s > c.n) s = c.n;
-				if (s > nb.pos) {
-					const uint32_t lits = s - nb.pos;
-					const uint32_t cs = lit_steps(nb.ctx_state, lits);
-					nb.pos = bs.pos = s; nb.ctx_state = bs.ctx_state = cs;
-					count = 8;
-					continue;
-				}
+
+	for (;;) {
+		if (phase == P_MODEL) {
+			/* the adaptive model the neighbour has at pick_pos: base model before the first base
+			 * packet at or after it (dense checkpoint + replay of < 64 bytes of base packets) ... */
+			if ((ch.n_ins + ch.n_rem) != 0 && !spilled) {
+				/* the model is about to overwrite the live lists (they share LDS): move the lists to a
+				 * global scratch slot and carry on from there */
+				uint32_t sl = 0;
+				if (lane == 0) sl = atomicAdd(big.spill_ctr, 1u);
+				sl = uni(sl);
+				if (sl >= big.slots) { ch.overflow = true; phase = P_OUT; continue; }
+				uint16_t* gik = big.ins_key + (size_t)sl * big.cap; uint32_t* gip = big.ins_pos + (size_t)sl * big.cap;
+				uint16_t* grk = big.rem_key + (size_t)sl * big.cap; uint32_t* grp = big.rem_pos + (size_t)sl * big.cap;
+				for (uint32_t i = lane; i < ch.n_ins; i += 64) { gik[i] = ch.ins_key[i]; gip[i] = ch.ins_pos[i]; }
+				for (uint32_t i = lane; i < ch.n_rem; i += 64) { grk[i] = ch.rem_key[i]; grp[i] = ch.rem_pos[i]; }
+				__threadfence_block();
+				wave_sync();
+				ch.ins_key = gik; ch.ins_pos = gip; ch.rem_key = grk; ch.rem_pos = grp;
+				ch.uctx = big.uctx + (size_t)sl * big.uctx_cap;
+				ch.cap = big.cap; ch.uctx_cap = big.uctx_cap;
+				spilled = true;
 			}
+			model_load(c, b, probs, T, pick_pos, lane);
+			if (pick_is_mutation) {
+				prof_mark(prof, 1, lane); /* model at target */
+				if (c.diag_stop == 2) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = probs[lane]; } return; }
+			}
+			/* ... with the touched contexts overridden by their re-simulated values */
+			if ((ch.n_ins + ch.n_rem) != 0) { sim_limit = pick_pos; sim_overlay = true; phase = P_SIM; }
+			else phase = P_TOPK;
 		}
-		if (nb.pos <= bs.pos && nb.pos < c.n) {
-			/* ---- next neighbour packet: repair rules of packet_slab_neighbour.c:82-117 */
-			const uint32_t p = nb.pos;
-			win_cover(win, c, b.slab, p, lane);
-			mgl_pk pk;
-			if (first_packet) {
-				pk = m_first; /* :169 the mutated packet is coded as is */
+		if (phase == P_SIM) {
+			const int64_t r = chain_sim(b, ch, T, sim_limit, sim_overlay ? probs : nullptr, lane, &too_many);
+			wave_sync();
+			if (too_many) { phase = P_OUT; continue; }
+			if (sim_overlay) phase = P_TOPK;
+			else { delta = r; prof_mark(prof, 4, lane); phase = P_OUT; }
+		}
+		if (phase == P_TOPK) {
+			walk_from_state(tw, nb);
+			walk_window(tw, c, b.slab, lane);
+			mgl_pk picked;
+			const bool ok = pick_from_top_k(c, tw, probs, T, lencost, pick_inc, pick_best, rng, lane, &picked);
+			if (pick_is_mutation) {
+				if (!ok) { generate_failed = true; phase = P_OUT; continue; }
+				m_first = picked;
+				journal_set(jn, pos, first, m_first, lane);
+				pick_is_mutation = false;
+				prof_mark(prof, 2, lane); /* top-K */
+				if (c.diag_stop == 3 || (c.diag_stop >= 31 && c.diag_stop <= 36)) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = (uint32_t)m_first; } return; }
 			} else {
-				if (count < 8) count++;
-				const mgl_pk old = (second_set && p == pos + 1) ? m_second : win_pk(win, p);
-				pk = old;
-				uint32_t type = mgl_pk_type(pk);
-				if (type == MGL_SHORT_REP || (type == MGL_LITERAL && count < 4)) {
-					const bool same = nb.dists[0] < p && win_byte(win, p) == c.data[p - nb.dists[0] - 1];
-					if (same) { if (count < 4) pk = MGL_PK_SHORT_REP; }
-					else pk = MGL_PK_LITERAL;
-				}
-				type = mgl_pk_type(pk);
-				if (type == MGL_LONG_REP) {
-					const uint32_t len = mgl_pk_len(pk);
-					uint32_t idx = mgl_pk_dist(pk);
-					walk_from_state(tw, nb);
-					bool ok = long_rep_ok(c, tw, idx, len, lane);
-					for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, tw, idx, len, lane); }
-					pk = mgl_pack(MGL_LONG_REP, idx, len);
-					if (!ok) {
-						if (!BIG && !spilled) {
-							/* the model is about to overwrite the live lists (they share LDS): move the
-							 * lists to a global scratch slot and carry on from there */
-							uint32_t sl = 0;
-							if (lane == 0) sl = atomicAdd(big.spill_ctr, 1u);
-							sl = uni(sl);
-							if (sl >= big.slots) { ch.overflow = true; break; }
-							uint16_t* gik = big.ins_key + (size_t)sl * big.cap; uint32_t* gip = big.ins_pos + (size_t)sl * big.cap;
-							uint16_t* grk = big.rem_key + (size_t)sl * big.cap; uint32_t* grp = big.rem_pos + (size_t)sl * big.cap;
-							for (uint32_t i = lane; i < ch.n_ins; i += 64) { gik[i] = ch.ins_key[i]; gip[i] = ch.ins_pos[i]; }
-							for (uint32_t i = lane; i < ch.n_rem; i += 64) { grk[i] = ch.rem_key[i]; grp[i] = ch.rem_pos[i]; }
-							__threadfence_block();
-							wave_sync();
-							ch.ins_key = gik; ch.ins_pos = gip; ch.rem_key = grk; ch.rem_pos = grp;
-							ch.uctx = big.uctx + (size_t)sl * big.uctx_cap;
-							ch.cap = big.cap; ch.uctx_cap = big.uctx_cap;
-							spilled = true;
+				picked_pk = ok ? picked : pick_inc;
+				have_pick = true;
+			}
+			win.base = 0xFFFFFFFFu;
+			phase = P_WALK;
+		}
+		if (phase == P_WALK) {
+			/* ---- two-pointer walk over neighbour packets (nb) and base packets (bs) */
+			bool request_pick = false;
+			while (nb.pos < c.n || bs.pos < c.n) {
+				if (ch.overflow || jn.overflow || too_many || ++guard > (BIG ? (1u << 20) : 4096u)) { ch.overflow = true; break; }
+				if (!first_packet && !have_pick && nb.pos == bs.pos && count >= 3) {
+					const bool same_ctx = nb.ctx_state == bs.ctx_state;
+					const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
+					                    nb.dists[3] == bs.dists[3];
+					if (same_ctx && same_d) break; /* the rest of the file is coded identically */
+					if (same_ctx && nb.ctx_state < 7) {
+						/* plain literals up to the next special packet code identically: skip them */
+						uint32_t sx = uni(sp_find_next(b, nb.pos));
+						if (sx == MGL_POS_INF || sx > c.n) sx = c.n;
+						if (sx > nb.pos) {
+							const uint32_t cs = lit_steps(nb.ctx_state, sx - nb.pos);
+							nb.pos = bs.pos = sx; nb.ctx_state = bs.ctx_state = cs;
+							count = 8;
+							continue;
 						}
-						const bool best = (nbr_draw(rng) % 4u) == 0;
-						/* the model at p needs every base packet that starts before p priced in */
-						while (bs.pos < p && !ch.overflow) {
-							win_cover(win, c, b.slab, bs.pos, lane);
-							const mgl_pk bpk = win_pk(win, bs.pos);
-							mgl_plan bpl;
-							plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);
-							changes_add<false>(ch, bpl, bs.pos, lane);
-							mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
-						}
-						if (ch.overflow) break;
-						model_at(c, b, ch, probs, T, p, lane, &too_many);
-						if (too_many) break;
-						walk_from_state(tw, nb);
-						walk_window(tw, c, b.slab, lane);
-						mgl_pk picked;
-						if (pick_from_top_k(c, tw, probs, T, lencost, pk, best, rng, lane, &picked)) pk = picked;
-						win_cover(win, c, b.slab, p, lane);
 					}
 				}
-				if (pk != old) {
-					const mgl_pk base_old = (second_set && p == pos + 1) ? uni64(b.slab[p]) : old;
-					journal_set(jn, p, base_old, pk, lane);
+				if ((have_pick || nb.pos <= bs.pos) && nb.pos < c.n) {
+					/* ---- next neighbour packet: repair rules of packet_slab_neighbour.c:82-117 */
+					const uint32_t p = nb.pos;
+					win_cover(win, c, b.slab, p, lane);
+					mgl_pk pk, old = 0;
+					if (have_pick) {
+						pk = picked_pk; old = resume_old; have_pick = false; /* back from the top-K pick for this packet */
+					} else if (first_packet) {
+						pk = m_first; /* :169 the mutated packet is coded as is */
+					} else {
+						if (count < 8) count++;
+						old = (second_set && p == pos + 1) ? m_second : win_pk(win, p);
+						pk = old;
+						uint32_t type = mgl_pk_type(pk);
+						if (type == MGL_SHORT_REP || (type == MGL_LITERAL && count < 4)) {
+							const bool same = nb.dists[0] < p && win_byte(win, p) == c.data[p - nb.dists[0] - 1];
+							if (same) { if (count < 4) pk = MGL_PK_SHORT_REP; }
+							else pk = MGL_PK_LITERAL;
+						}
+						type = mgl_pk_type(pk);
+						if (type == MGL_LONG_REP) {
+							const uint32_t len = mgl_pk_len(pk);
+							uint32_t idx = mgl_pk_dist(pk);
+							walk_from_state(tw, nb);
+							bool ok = long_rep_ok(c, tw, idx, len, lane);
+							for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, tw, idx, len, lane); }
+							pk = mgl_pack(MGL_LONG_REP, idx, len);
+							if (!ok) {
+								pick_best = (nbr_draw(rng) % 4u) == 0;
+								/* the model at p needs every base packet that starts before p priced in */
+								while (bs.pos < p && !ch.overflow) {
+									win_cover(win, c, b.slab, bs.pos, lane);
+									const mgl_pk bpk = win_pk(win, bs.pos);
+									mgl_plan bpl;
+									plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);
+									changes_add<false>(ch, bpl, bs.pos, lane);
+									mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
+								}
+								if (ch.overflow) break;
+								resume_old = old; pick_pos = p; pick_inc = pk;
+								request_pick = true;
+								break; /* -> P_MODEL, then back here with have_pick */
+							}
+						}
+					}
+					if (!first_packet && pk != old) {
+						const mgl_pk base_old = (second_set && p == pos + 1) ? uni64(b.slab[p]) : old;
+						journal_set(jn, p, base_old, pk, lane);
+					}
+					first_packet = false;
+					walked++;
+					const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
+					mgl_plan npl;
+					plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+					bool cancelled = false;
+					if (bs.pos == p) {
+						/* the base packet at the same position: identical coding cancels */
+						const mgl_pk bpk = win_pk(win, p);
+						const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
+						mgl_plan bpl;
+						plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
+						cancelled = bpk == pk && nb.ctx_state == bs.ctx_state &&
+						            (ntype != MGL_LITERAL || nb.ctx_state < 7 || npl.match_byte == bpl.match_byte);
+						if (!cancelled) changes_add<false>(ch, bpl, p, lane);
+						mgl_advance(&bs, btype, bdist, blen);
+					}
+					if (!cancelled) changes_add<true>(ch, npl, p, lane);
+					mgl_advance(&nb, ntype, ndist, nlen);
+				} else {
+					/* ---- a base packet the neighbour has already passed over: its events go away */
+					win_cover(win, c, b.slab, bs.pos, lane);
+					const mgl_pk bpk = win_pk(win, bs.pos);
+					mgl_plan bpl;
+					plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);
+					changes_add<false>(ch, bpl, bs.pos, lane);
+					mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
 				}
 			}
-			first_packet = false;
-			walked++;
-			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
-			mgl_plan npl;
-			plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
-			bool cancelled = false;
-			if (bs.pos == p) {
-				/* the base packet at the same position: identical coding cancels */
-				const mgl_pk bpk = win_pk(win, p);
-				const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
-				mgl_plan bpl;
-				plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
-				cancelled = bpk == pk && nb.ctx_state == bs.ctx_state &&
-				            (ntype != MGL_LITERAL || nb.ctx_state < 7 || npl.match_byte == bpl.match_byte);
-				if (!cancelled) changes_add<false>(ch, bpl, p, lane);
-				mgl_advance(&bs, btype, bdist, blen);
-			}
-			if (!cancelled) changes_add<true>(ch, npl, p, lane);
-			mgl_advance(&nb, ntype, ndist, nlen);
-		} else {
-			/* ---- a base packet the neighbour has already passed over: its events go away */
-			win_cover(win, c, b.slab, bs.pos, lane);
-			const mgl_pk bpk = win_pk(win, bs.pos);
-			mgl_plan bpl;
-			plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);
-			changes_add<false>(ch, bpl, bs.pos, lane);
-			mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
+			if (request_pick) { phase = P_MODEL; continue; }
+			prof_mark(prof, 3, lane); /* window walk */
+			if (c.diag_stop == 4) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = ch.n_ins + ch.n_rem; } return; }
+			if (ch.overflow || jn.overflow || too_many) { phase = P_OUT; continue; }
+			sim_limit = MGL_POS_INF; sim_overlay = false; phase = P_SIM;
+			continue;
 		}
+		if (phase == P_OUT) break;
 	}
 
-	prof_mark(prof, 3, lane); /* window walk */
-	if (c.diag_stop == 4) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = ch.n_ins + ch.n_rem; } return; }
-	int64_t delta = 0;
-	if (!ch.overflow && !jn.overflow && !too_many) delta = chain_sim(b, ch, T, MGL_POS_INF, nullptr, lane, &too_many);
-	prof_mark(prof, 4, lane); /* chain re-simulation */
+	if (generate_failed) { /* no candidate at the target (main.c:81-84 retries those) */
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+		return;
+	}
 	if (jn.overflow) { /* same rule as the full-walk path and the oracle: dropped */
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; }
 		return;
 	}
 	if (ch.overflow || too_many) {
-		/* does not fit the LDS change lists: hand it to the full-walk kernel */
+		/* does not fit the change lists: hand it to the next pass (BIG, then the full-walk kernel) */
 		if (lane == 0) {
-			const uint32_t slot = atomicAdd(todo_count, 1u);
-			todo[slot] = j;
+			const uint32_t slot2 = atomicAdd(todo_count, 1u);
+			todo[slot2] = j;
 			atomicAdd((unsigned long long*)(BIG ? &ctl->fallback_nbrs : &ctl->big_nbrs), 1ull);
 			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
 		}

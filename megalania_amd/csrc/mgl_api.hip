@@ -315,8 +315,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMemset(b.ch_ev, 0, sizeof(uint16_t) * ((size_t)b.pool_cap + 256)));
 		HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
 		if (sa->cfg.flags & MGL_F_PROFILE) {
-			HIPCHK(hipMalloc(&sa->d_prof, sizeof(unsigned long long) * 24));
-			HIPCHK(hipMemset(sa->d_prof, 0, sizeof(unsigned long long) * 24));
+			HIPCHK(hipMalloc(&sa->d_prof, sizeof(unsigned long long) * (32 + K)));
+			HIPCHK(hipMemset(sa->d_prof, 0, sizeof(unsigned long long) * (32 + K)));
 		}
 		HIPCHK(hipMalloc(&sa->d_todo, sizeof(uint32_t) * (K + 1)));
 		HIPCHK(hipMemset(sa->d_todo, 0, sizeof(uint32_t) * (K + 1)));
@@ -737,7 +737,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 6: src = b.sp_state; sz = sizeof(uint32_t) * 8 * (size_t)sa->n; break;
 	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
-	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * 24 : 0; break;
+	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
 	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
 	}

@@ -537,6 +537,7 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
 	uint32_t slot = 0;
+	const unsigned long long t_begin = prof_acc ? __builtin_readcyclecounter() : 0ull;
 	if (BIG) {
 		slot = j;
 		const uint32_t nflag = *big.todo_in_count;
@@ -860,4 +861,5 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 		nd++;
 	}
 	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; }
+	if (prof_acc && lane == 0) prof_acc[32 + j] = __builtin_readcyclecounter() - t_begin; /* diagnostic: wave lifetime */
 }

@@ -77,6 +77,8 @@ typedef struct {
                              both engines return identical numbers */
 
 #define MGL_F_PROFILE 4u  /* diagnostic: per-phase cycle counters in the neighbour kernel */
+#define MGL_F_NO_SNAPSHOTS 8u /* do not keep device copies of the all-literal / best base structures:
+                              * mgl_sa_begin_epoch then re-derives them from the slab (less memory, slower) */
 
 typedef struct {
 	uint64_t steps;          /* SA steps executed by this call */

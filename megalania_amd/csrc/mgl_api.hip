@@ -87,6 +87,10 @@ struct mgl_sa {
 	ApplyBuf ab;
 	uint32_t apply_blocks;
 	bool incremental_apply;
+	/* copies of the base structures of the all-literal slab and of the best slab (main.c:71-77) */
+	bool snapshots;
+	Base2 snap_lit, snap_best;
+	SnapMeta* d_snap_meta; /* [0] literal, [1] best */
 	hipEvent_t ev_begin, ev_end;
 	std::vector<hipEvent_t> ev_pool;
 };
@@ -120,6 +124,75 @@ static hipError_t alloc_base(BaseMem& b, uint32_t n, uint32_t ckpt_elems)
 	return hipMemset(b.ctl, 0, sizeof(Control));
 }
 
+static size_t b2_pool_entries(const Base2& b) { return (size_t)b.pool_cap + 256; }
+/* device arrays of the incremental base; `own_slab`: also the slab and the on-walk bitmap */
+static int alloc_b2(Base2& b, size_t n, bool own_slab, bool init, size_t* bytes_out)
+{
+	size_t bytes = 0;
+	if (own_slab) {
+		HIPCHK(hipMalloc(&b.slab, sizeof(mgl_pk) * n)); bytes += sizeof(mgl_pk) * n;
+		HIPCHK(hipMalloc(&b.onwalk, sizeof(uint64_t) * ((n + 63) / 64 + 1)));
+	}
+	HIPCHK(hipMalloc(&b.sp0, sizeof(uint64_t) * (b.nw0 + 64))); bytes += sizeof(uint64_t) * (b.nw0 + 64);
+	HIPCHK(hipMalloc(&b.sp1, sizeof(uint64_t) * (b.nw1 + 64)));
+	HIPCHK(hipMalloc(&b.sp2, sizeof(uint64_t) * (b.nw2 + 64)));
+	HIPCHK(hipMalloc(&b.sp_state, sizeof(uint32_t) * 8 * n)); bytes += sizeof(uint32_t) * 8 * n;
+	HIPCHK(hipMalloc(&b.ck_probs, sizeof(uint16_t) * (size_t)b.nck * b.ck_elems)); bytes += sizeof(uint16_t) * (size_t)b.nck * b.ck_elems;
+	HIPCHK(hipMalloc(&b.ch_off, sizeof(uint32_t) * b.ck_elems));
+	HIPCHK(hipMalloc(&b.ch_len, sizeof(uint32_t) * b.ck_elems));
+	HIPCHK(hipMalloc(&b.ch_cap, sizeof(uint32_t) * b.ck_elems));
+	HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * b2_pool_entries(b))); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
+	HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * b2_pool_entries(b))); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
+	HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
+	if (init) {
+		HIPCHK(hipMemset(b.sp0, 0, sizeof(uint64_t) * (b.nw0 + 64)));
+		HIPCHK(hipMemset(b.sp1, 0, sizeof(uint64_t) * (b.nw1 + 64)));
+		HIPCHK(hipMemset(b.sp2, 0, sizeof(uint64_t) * (b.nw2 + 64)));
+		HIPCHK(hipMemset(b.ch_pos, 0xFF, sizeof(uint32_t) * b2_pool_entries(b)));
+		HIPCHK(hipMemset(b.ch_ev, 0, sizeof(uint16_t) * b2_pool_entries(b)));
+	}
+	if (bytes_out) *bytes_out = bytes;
+	return MGL_OK;
+}
+static void free_b2(Base2& b, bool own_slab)
+{
+	if (own_slab) { dfree(b.slab); dfree(b.onwalk); }
+	dfree(b.sp0); dfree(b.sp1); dfree(b.sp2); dfree(b.sp_state); dfree(b.ck_probs);
+	dfree(b.ch_off); dfree(b.ch_len); dfree(b.ch_cap); dfree(b.ch_pos); dfree(b.ch_ev); dfree(b.pool_top);
+	memset(&b, 0, sizeof b);
+}
+/* dir 0: base -> snapshot, dir 1: snapshot -> base; cond: only if this step found a new best */
+static int launch_snapshot(mgl_sa* sa, Base2& snap, uint32_t which, int dir, int cond)
+{
+	const Base2& from = dir == 0 ? sa->b2 : snap;
+	const Base2& to = dir == 0 ? snap : sa->b2;
+	const size_t n = sa->n;
+	SnapPlan p;
+	memset(&p, 0, sizeof p);
+	uint32_t k = 0;
+	auto seg = [&](const void* s, void* d, size_t bytes, uint32_t pool_elem) {
+		p.seg[k].src = s; p.seg[k].dst = d; p.seg[k].bytes = bytes; p.seg[k].pool_elem = pool_elem; k++;
+	};
+	seg(from.slab, to.slab, sizeof(mgl_pk) * n, 0);
+	seg(from.onwalk, to.onwalk, sizeof(uint64_t) * ((n + 63) / 64 + 1), 0);
+	seg(from.sp0, to.sp0, sizeof(uint64_t) * (from.nw0 + 64), 0);
+	seg(from.sp1, to.sp1, sizeof(uint64_t) * (from.nw1 + 64), 0);
+	seg(from.sp2, to.sp2, sizeof(uint64_t) * (from.nw2 + 64), 0);
+	seg(from.sp_state, to.sp_state, sizeof(uint32_t) * 8 * n, 0);
+	seg(from.ck_probs, to.ck_probs, sizeof(uint16_t) * (size_t)from.nck * from.ck_elems, 0);
+	seg(from.ch_off, to.ch_off, sizeof(uint32_t) * from.ck_elems, 0);
+	seg(from.ch_len, to.ch_len, sizeof(uint32_t) * from.ck_elems, 0);
+	seg(from.ch_cap, to.ch_cap, sizeof(uint32_t) * from.ck_elems, 0);
+	seg(from.ch_pos, to.ch_pos, sizeof(uint32_t) * b2_pool_entries(from), 4);
+	seg(from.ch_ev, to.ch_ev, sizeof(uint16_t) * b2_pool_entries(from), 2);
+	seg(from.pool_top, to.pool_top, sizeof(uint32_t), 0);
+	p.nseg = k;
+	p.src_pool_top = from.pool_top;
+	hipLaunchKernelGGL(k_snapshot, dim3(2048), dim3(256), 0, sa->stream, p, sa->base.ctl, sa->d_snap_meta + which, dir, cond);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
+
 static int launch_rebuild(mgl_sa* sa, BaseMem& b, int from_dirty, uint64_t* cum, uint16_t* final_probs)
 {
 	hipLaunchKernelGGL(k_rebuild, dim3(1), dim3(64), sa->walk_lds, sa->stream, sa->ctx, b.v, b.ctl, from_dirty, cum, final_probs);
@@ -142,6 +215,10 @@ static int launch_apply(mgl_sa* sa)
 	                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
+	if (sa->snapshots) {
+		int rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1);
+		if (rc) return rc;
+	}
 	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
@@ -203,9 +280,9 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
-	dfree(sa->b2.sp0); dfree(sa->b2.sp1); dfree(sa->b2.sp2); dfree(sa->b2.sp_state); dfree(sa->b2.ck_probs);
-	dfree(sa->b2.ch_off); dfree(sa->b2.ch_len); dfree(sa->b2.ch_cap); dfree(sa->b2.ch_pos); dfree(sa->b2.ch_ev);
-	dfree(sa->b2.pool_top); dfree(sa->d_todo); dfree(sa->d_prof);
+	free_b2(sa->b2, false);
+	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
+	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
 	dfree(sa->d_todo2); dfree(sa->d_counts);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
@@ -298,22 +375,23 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		b.ck_elems = ckpt_elems;
 		b.pool_cap = (uint32_t)(24 * n + (size_t)L.total * 272 + 4096);
 		size_t bytes = 0;
-		HIPCHK(hipMalloc(&b.sp0, sizeof(uint64_t) * (b.nw0 + 64))); bytes += sizeof(uint64_t) * (b.nw0 + 64);
-		HIPCHK(hipMalloc(&b.sp1, sizeof(uint64_t) * (b.nw1 + 64)));
-		HIPCHK(hipMalloc(&b.sp2, sizeof(uint64_t) * (b.nw2 + 64)));
-		HIPCHK(hipMemset(b.sp0, 0, sizeof(uint64_t) * (b.nw0 + 64)));
-		HIPCHK(hipMemset(b.sp1, 0, sizeof(uint64_t) * (b.nw1 + 64)));
-		HIPCHK(hipMemset(b.sp2, 0, sizeof(uint64_t) * (b.nw2 + 64)));
-		HIPCHK(hipMalloc(&b.sp_state, sizeof(uint32_t) * 8 * n)); bytes += sizeof(uint32_t) * 8 * n;
-		HIPCHK(hipMalloc(&b.ck_probs, sizeof(uint16_t) * (size_t)b.nck * ckpt_elems)); bytes += sizeof(uint16_t) * (size_t)b.nck * ckpt_elems;
-		HIPCHK(hipMalloc(&b.ch_off, sizeof(uint32_t) * ckpt_elems));
-		HIPCHK(hipMalloc(&b.ch_len, sizeof(uint32_t) * ckpt_elems));
-		HIPCHK(hipMalloc(&b.ch_cap, sizeof(uint32_t) * ckpt_elems));
-		HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * ((size_t)b.pool_cap + 256))); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
-		HIPCHK(hipMemset(b.ch_pos, 0xFF, sizeof(uint32_t) * ((size_t)b.pool_cap + 256)));
-		HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * ((size_t)b.pool_cap + 256))); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
-		HIPCHK(hipMemset(b.ch_ev, 0, sizeof(uint16_t) * ((size_t)b.pool_cap + 256)));
-		HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
+		{
+			int rc = alloc_b2(b, n, false, true, &bytes);
+			if (rc) return rc;
+		}
+		sa->snapshots = !(sa->cfg.flags & MGL_F_NO_SNAPSHOTS);
+		if (sa->snapshots) {
+			for (Base2* s : { &sa->snap_lit, &sa->snap_best }) {
+				*s = b;
+				s->slab = nullptr; s->onwalk = nullptr; s->sp0 = s->sp1 = s->sp2 = nullptr; s->sp_state = nullptr;
+				s->ck_probs = nullptr; s->ch_off = s->ch_len = s->ch_cap = s->ch_pos = nullptr; s->ch_ev = nullptr;
+				s->pool_top = nullptr;
+				int rc = alloc_b2(*s, n, true, false, nullptr);
+				if (rc) return rc;
+			}
+			HIPCHK(hipMalloc(&sa->d_snap_meta, sizeof(SnapMeta) * 2));
+			HIPCHK(hipMemset(sa->d_snap_meta, 0, sizeof(SnapMeta) * 2));
+		}
 		if (sa->cfg.flags & MGL_F_PROFILE) {
 			HIPCHK(hipMalloc(&sa->d_prof, sizeof(unsigned long long) * (32 + K)));
 			HIPCHK(hipMemset(sa->d_prof, 0, sizeof(unsigned long long) * (32 + K)));
@@ -390,6 +468,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipGetLastError());
 	int rc = rebuild_base(sa, 0);
 	if (rc) return rc;
+	if (sa->incremental && sa->snapshots && (rc = launch_snapshot(sa, sa->snap_lit, 0, 0, 0))) return rc;
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	return MGL_OK;
 }
@@ -437,17 +516,32 @@ extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 {
 	if (!sa) return fail(MGL_EINVAL, "null handle");
 	HIPCHK(hipSetDevice(sa->device));
-	if (from_best) HIPCHK(hipMemcpyAsync(sa->base.v.slab, sa->d_best, sizeof(mgl_pk) * (size_t)sa->n, hipMemcpyDeviceToDevice, sa->stream));
-	else {
-		hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
-		HIPCHK(hipGetLastError());
-	}
 	Control c;
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
 	c.iter = 0; c.cur_cost = 0; c.phase = phase; c.accepted_flag = 0; c.copy_best_flag = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
+	const bool snaps = sa->incremental && sa->snapshots;
+	if (from_best && c.best_cost == 0) from_best = 0; /* no best yet: packets_best is still the all-literal slab */
+	if (snaps) {
+		SnapMeta meta[2];
+		HIPCHK(hipMemcpyAsync(meta, sa->d_snap_meta, sizeof meta, hipMemcpyDeviceToHost, sa->stream));
+		HIPCHK(hipStreamSynchronize(sa->stream));
+		const uint32_t which = from_best ? 1u : 0u;
+		if (meta[which].valid) {
+			if ((rc = launch_snapshot(sa, which ? sa->snap_best : sa->snap_lit, which, 1, 0))) return rc;
+			HIPCHK(hipStreamSynchronize(sa->stream));
+			return MGL_OK;
+		}
+	}
+	if (from_best) HIPCHK(hipMemcpyAsync(sa->base.v.slab, sa->d_best, sizeof(mgl_pk) * (size_t)sa->n, hipMemcpyDeviceToDevice, sa->stream));
+	else {
+		hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
+		HIPCHK(hipGetLastError());
+	}
 	if ((rc = rebuild_base(sa, 0))) return rc;
+	/* the base now is the best (or the literal) slab's: keep it for the next epoch */
+	if (snaps && (rc = launch_snapshot(sa, from_best ? sa->snap_best : sa->snap_lit, from_best ? 1u : 0u, 0, 0))) return rc;
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	return MGL_OK;
 }
@@ -506,6 +600,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 			HIPCHK(hipGetLastError());
 			if ((rc = rebuild_base(sa, 1))) return rc;
+			if (sa->incremental && sa->snapshots && (rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1))) return rc;
 		}
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 	}
@@ -589,6 +684,7 @@ extern "C" int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t p
 	if (rc) return rc;
 	if (c.rebuild_cost != perplexity) return fail(MGL_EINVAL, "mgl_sa_set_best: perplexity does not match the slab");
 	HIPCHK(hipMemcpyAsync(sa->d_best, sa->scratch.v.slab, sizeof(mgl_pk) * (size_t)sa->n, hipMemcpyDeviceToDevice, sa->stream));
+	if (sa->d_snap_meta) HIPCHK(hipMemsetAsync(sa->d_snap_meta + 1, 0, sizeof(SnapMeta), sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
 	c.best_cost = perplexity;
 	return write_ctl(sa, sa->base, &c);

@@ -178,3 +178,44 @@ def test_incremental_accept_equals_rebuild(name, K, steps, golden, golden_input)
     assert accepted > 5
     inc.close()
     ref.close()
+
+
+@pytest.mark.parametrize("name,K", [("lorem4k", 64), ("enwik3k", 96)])
+def test_epoch_snapshots_equal_rebuild(name, K, golden, golden_input):
+    """mgl_sa_begin_epoch restores the all-literal / best base structures from device copies;
+    the chain must be indistinguishable from one that re-derives them from the slab
+    (MGL_F_NO_SNAPSHOTS), across main.c:69-77's phase/epoch schedule."""
+    data = golden_input(name)
+    steps = (len(data) + K - 1) // K
+    a = binding.SA(data, neighbours_per_step=K, seed=11, iters_per_epoch=len(data))
+    b = binding.SA(data, neighbours_per_step=K, seed=11, iters_per_epoch=len(data), snapshots=False)
+    o = Oracle(data, dict_limit=0x400000)
+    for phase in range(3):
+        for epoch in range(3):
+            for sa in (a, b):
+                sa.begin_epoch(phase, from_best=phase != 0)
+            ca, costa = a.current()
+            cb, costb = b.current()
+            assert costa == costb and (ca == cb).all(), (phase, epoch, "start")
+            assert costa == o.cost_slab(ca.astype(literal_slab(1).dtype))["total"]
+            assert_same_base(canonical_base(a, ca), canonical_base(b, cb), (name, phase, epoch, "restored"))
+            sta, stb = a.run(steps), b.run(steps)
+            for k in ("evaluations", "accepted", "improved", "current_cost", "best_cost", "packets"):
+                assert sta[k] == stb[k], (phase, epoch, k)
+            ca, _ = a.current()
+            cb, _ = b.current()
+            assert (ca == cb).all()
+            assert_same_base(canonical_base(a, ca), canonical_base(b, cb), (name, phase, epoch, "end"))
+    ba, bca = a.best()
+    bb, bcb = b.best()
+    assert bca == bcb and (ba == bb).all() and bca == o.cost_slab(ba.astype(literal_slab(1).dtype))["total"]
+    # a best slab pushed in from outside (the multi-GPU exchange) invalidates the device copy
+    lit = literal_slab(len(data))
+    a.set_best(lit, o.cost_slab(lit)["total"])
+    a.begin_epoch(1, from_best=True)
+    cur, cost = a.current()
+    assert (cur == lit.astype(cur.dtype)).all() and cost == o.cost_slab(lit)["total"]
+    st = a.run(3)
+    assert st["evaluations"] > 0
+    a.close()
+    b.close()

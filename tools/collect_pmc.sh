@@ -25,5 +25,6 @@ out = dict(kernel="k_neighbours2<false>", workload="c2, 4096 neighbours/launch, 
            fetch_bytes_raw=f * 1024, fetch_bytes_doubled=2 * f * 1024, write_bytes=w * 1024,
            bytes_per_launch=2 * f * 1024 + w * 1024)
 json.dump(out, open("$ROOT/profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(out, open("$ROOT/gpurun_out/pmc_traffic.json", "w"), indent=1)  # gpurun merges only gpurun_out/ back: copy it into profiles/
 print(json.dumps(out))
 PY

@@ -77,6 +77,7 @@ typedef struct {
                              both engines return identical numbers */
 
 #define MGL_F_PROFILE 4u  /* diagnostic: per-phase cycle counters in the neighbour kernel */
+#define MGL_F_SERIAL_BUILD 16u /* derive the base structures with the one-wavefront builder only (diagnostic) */
 #define MGL_F_NO_SNAPSHOTS 8u /* do not keep device copies of the all-literal / best base structures:
                               * mgl_sa_begin_epoch then re-derives them from the slab (less memory, slower) */
 

@@ -26,6 +26,7 @@ F_TIMING = 1
 F_FULLWALK = 2
 F_PROFILE = 4
 F_NO_SNAPSHOTS = 8
+F_SERIAL_BUILD = 16
 
 HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
@@ -155,7 +156,7 @@ class SA:
 
     def __init__(self, data: bytes, neighbours_per_step=4096, seed=1673551, top_k=20, lc=0, lp=0, pb=0,
                  dict_limit=0, max_bucket_scan=0, iters_per_epoch=0, device=0, timing=False, fullwalk=False,
-                 snapshots=True, flags=0):
+                 snapshots=True, serial_build=False, flags=0):
         self.L = hip_lib()
         if self.L.mgl_device_count() < 1:
             raise MglError("no HIP device visible: the search path has no CPU implementation")
@@ -165,7 +166,7 @@ class SA:
         self.props = Properties(lc, lp, pb)
         self.cfg = Config(seed, neighbours_per_step, top_k, dict_limit, max_bucket_scan, iters_per_epoch, device,
                           (F_TIMING if timing else 0) | (F_FULLWALK if fullwalk else 0)
-                          | (0 if snapshots else F_NO_SNAPSHOTS) | flags)
+                          | (0 if snapshots else F_NO_SNAPSHOTS) | (F_SERIAL_BUILD if serial_build else 0) | flags)
         self.h = self.L.mgl_sa_create(_ptr(self.data), self.n, self.props, C.byref(self.cfg))
         if not self.h:
             raise MglError(self.L.mgl_last_error().decode())

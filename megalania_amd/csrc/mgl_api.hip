@@ -5,6 +5,7 @@
 #include "mgl_kernels.hip"
 #include "mgl_kernels2.hip"
 #include "mgl_kernels3.hip"
+#include "mgl_pbuild.hip"
 #include "../../include/megalania_hip.h"
 
 #include <math.h>
@@ -91,6 +92,8 @@ struct mgl_sa {
 	bool snapshots;
 	Base2 snap_lit, snap_best;
 	SnapMeta* d_snap_meta; /* [0] literal, [1] best */
+	bool parallel_build;
+	PBuild pb;
 	hipEvent_t ev_begin, ev_end;
 	std::vector<hipEvent_t> ev_pool;
 };
@@ -200,9 +203,36 @@ static int launch_rebuild(mgl_sa* sa, BaseMem& b, int from_dirty, uint64_t* cum,
 	return MGL_OK;
 }
 /* (re)derive everything that hangs off the current base slab */
+/* the base structures of the slab from scratch, block-parallel (mgl_pbuild.hip) */
+static int launch_pbuild(mgl_sa* sa)
+{
+	const DevCtx& c = sa->ctx;
+	Base2& b = sa->b2;
+	PBuild& pb = sa->pb;
+	Control* ctl = sa->base.ctl;
+	hipStream_t st = sa->stream;
+	const uint32_t total = c.L.total;
+	hipLaunchKernelGGL(pb_exits, dim3(pb.nblk), dim3(320), 0, st, c, b, pb);
+	hipLaunchKernelGGL(pb_entries, dim3(1), dim3(64), 0, st, c, pb);
+	hipLaunchKernelGGL(pb_mark, dim3((pb.nblk + 63) / 64), dim3(64), 0, st, c, b, pb, ctl);
+	hipLaunchKernelGGL(pb_scan, dim3(1), dim3(64), 0, st, pb);
+	hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
+	hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
+	hipLaunchKernelGGL(pb_walk<false>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
+	hipLaunchKernelGGL(pb_offsets, dim3((b.ck_elems + 255) / 256), dim3(256), 0, st, b, pb, total);
+	hipLaunchKernelGGL(pb_layout, dim3(1), dim3(64), 0, st, b, pb, ctl, total);
+	hipLaunchKernelGGL(pb_walk<true>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
+	hipLaunchKernelGGL(pb_sim, dim3((pb.seg_cap + 63) / 64), dim3(64), 0, st, c, b, pb);
+	hipLaunchKernelGGL(pb_sim_fix, dim3((total + 63) / 64), dim3(64), 0, st, c, b, pb);
+	hipLaunchKernelGGL(pb_ckpt, dim3((b.ck_elems + 63) / 64, (b.nck + MGL_PB_CK_ROWS - 1) / MGL_PB_CK_ROWS), dim3(64), 0, st, c, b);
+	hipLaunchKernelGGL(pb_finish, dim3(1), dim3(64), 0, st, pb, ctl);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
 static int rebuild_base(mgl_sa* sa, int after_accept)
 {
 	if (!sa->incremental) return launch_rebuild(sa, sa->base, after_accept, nullptr, nullptr);
+	if (sa->parallel_build && !after_accept) return launch_pbuild(sa);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, after_accept);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
@@ -282,6 +312,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	free_b2(sa->b2, false);
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
+	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
+	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
 	dfree(sa->d_todo2); dfree(sa->d_counts);
@@ -378,6 +410,24 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		{
 			int rc = alloc_b2(b, n, false, true, &bytes);
 			if (rc) return rc;
+		}
+		sa->parallel_build = !(sa->cfg.flags & MGL_F_SERIAL_BUILD);
+		if (sa->parallel_build) {
+			PBuild& pb = sa->pb;
+			memset(&pb, 0, sizeof pb);
+			pb.shift = n <= (1u << 20) ? 8u : n <= (1u << 23) ? 9u : MGL_PB_MAX_SHIFT;
+			pb.nblk = (uint32_t)((n + (1u << pb.shift) - 1) >> pb.shift);
+			HIPCHK(hipMalloc(&pb.exits, sizeof(uint16_t) * (size_t)pb.nblk * MGL_PB_ENTRIES));
+			HIPCHK(hipMalloc(&pb.entry, sizeof(uint32_t) * ((size_t)pb.nblk + 1)));
+			HIPCHK(hipMalloc(&pb.tf_ctx, sizeof(uint64_t) * pb.nblk));
+			HIPCHK(hipMalloc(&pb.tf_dist, sizeof(uint32_t) * 8 * (size_t)pb.nblk));
+			HIPCHK(hipMalloc(&pb.tf_pk, sizeof(uint32_t) * pb.nblk));
+			HIPCHK(hipMalloc(&pb.st_in, sizeof(uint32_t) * 8 * (size_t)pb.nblk));
+			HIPCHK(hipMalloc(&pb.hist, sizeof(uint32_t) * (size_t)pb.nblk * ckpt_elems));
+			HIPCHK(hipMalloc(&pb.acc, sizeof(unsigned long long) * 8));
+			pb.seg_cap = b.pool_cap / MGL_PB_SEG + ckpt_elems + 64u;
+			HIPCHK(hipMalloc(&pb.seg_off, sizeof(uint32_t) * (ckpt_elems + 1)));
+			HIPCHK(hipMalloc(&pb.unres, pb.seg_cap));
 		}
 		sa->snapshots = !(sa->cfg.flags & MGL_F_NO_SNAPSHOTS);
 		if (sa->snapshots) {
@@ -835,6 +885,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
 	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
+	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
 	}
 	*bytes = sz;
@@ -843,10 +894,11 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	return MGL_OK;
 }
 
-/* diagnostic knobs (tools/): key 0 = stop the neighbour kernel after phase `value` */
+/* diagnostic knobs (tools/, tests/): key 0 = stop the neighbour kernel after phase `value`; key 1 = see below */
 extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
 {
 	if (!sa) return fail(MGL_EINVAL, "null handle");
 	if (key == 0) { sa->ctx.diag_stop = (uint32_t)value; return MGL_OK; }
+	if (key == 1) { sa->pb.force_fix = (uint32_t)value; return MGL_OK; } /* parallel builder: redo every chain segment serially */
 	return fail(MGL_EINVAL, "mgl_debug_set: unknown key");
 }

@@ -1,0 +1,517 @@
+/*
+ * mgl_pbuild.hip -- deriving the base structures of a slab in parallel.
+ *
+ * k_build (mgl_kernels2.hip) walks the slab with one wavefront: fine for a per-step fallback on
+ * small inputs, 135 ms at 100 KB and 14 s at 10 MB.  The same structures, bit for bit, from a
+ * pipeline of wide kernels over blocks of 2^shift (256..1024) positions:
+ *
+ *   pb_exits    per block, for each of the 273 offsets a walk can enter it at: where it leaves
+ *   pb_entries  chase those maps block to block: the first on-walk position of every block
+ *   pb_mark     one thread per block: on-walk and special bitmaps, packet count, and the block's
+ *               effect on (ctx_state, rep distances) as a composable transform
+ *   pb_scan     compose the transforms in block order: the walk state every block starts in
+ *   pb_levels   summary levels of the special bitmap
+ *   pb_walk<0>  one wavefront per block: special-state records, events per context
+ *   pb_offsets  per context, exclusive scan of the per-block counts; pb_layout: chain offsets
+ *   pb_walk<1>  the same walk again: every event to its slot of its context's chain
+ *   pb_sim      per 2048-event chain segment: the probability before each event, the cost (+ pb_sim_fix)
+ *   pb_ckpt     dense checkpoints read off the chains, written as 128-byte rows
+ *   pb_finish   totals into Control
+ *
+ * Everything the walk needs at a block boundary is carried by the scan, so no kernel is serial in
+ * the file size except pb_entries / pb_scan (one LDS-staged pointer chase, 32 bytes per KiB of
+ * input).  Integer work throughout; results are identical to k_build's (tests/test_gpu_incremental.py).
+ */
+#include "mgl_base2.h"
+
+#define MGL_PB_MAX_SHIFT 10u  /* block = 2^shift positions, shift chosen per input size (8..10) */
+#define MGL_PB_MAX_BLOCK (1u << MGL_PB_MAX_SHIFT)
+#define MGL_PB_SEG 2048u      /* pb_sim: events per thread ... */
+#define MGL_PB_WARM 1024u     /* ... after this many events of warm-up from both ends of the probability range */
+#define MGL_PB_ENTRIES 273u /* a packet starting before a block boundary ends at most 272 bytes past it */
+#define MGL_PB_CK_ROWS 64u
+
+struct PBuild {
+	uint32_t nblk, shift;
+	uint16_t* exits;    /* nblk x MGL_PB_ENTRIES: offset past the block end a walk entering at offset e leaves at */
+	uint32_t* entry;    /* nblk + 1: first on-walk position >= blk << shift */
+	uint64_t* tf_ctx;   /* nblk: ctx_state after the block for each of the 12 states before it, 4 bits each */
+	uint32_t* tf_dist;  /* nblk x 8: value[4], source[4] (0..3 = rep distance i before the block, 4 = value) */
+	uint32_t* tf_pk;    /* nblk: packets starting in the block */
+	uint32_t* st_in;    /* nblk x 8: ctx_state, dists[4] at the block's first packet */
+	uint32_t* hist;     /* nblk x ck_elems: events per context, then their exclusive scan over blocks */
+	unsigned long long* acc; /* [0] cost [1] packets [2] final ctx_state [3..6] final dists [7] segments pb_sim_fix redid */
+	uint32_t* seg_off;  /* total + 1: first pb_sim segment of each context */
+	uint8_t* unres;     /* per segment: warm-up did not pin the probability, left to pb_sim_fix */
+	uint32_t seg_cap;
+	uint32_t force_fix; /* diagnostic: treat every warm-up as inconclusive (exercises pb_sim_fix) */
+};
+
+/* the validity rule of k_build: anything that is not a packet that fits is walked as a literal */
+__device__ __forceinline__ bool pb_decode(mgl_pk pk, uint32_t pos, uint32_t n, uint32_t& type, uint32_t& dist, uint32_t& len)
+{
+	type = mgl_pk_type(pk); len = mgl_pk_len(pk); dist = mgl_pk_dist(pk);
+	if (type < MGL_LITERAL || type > MGL_LONG_REP || len == 0 || pos + len > n) {
+		type = MGL_LITERAL; len = 1; dist = 0;
+		return false;
+	}
+	return true;
+}
+
+__global__ void __launch_bounds__(320) pb_exits(DevCtx c, Base2 b, PBuild pb)
+{
+	__shared__ uint16_t lens[MGL_PB_MAX_BLOCK];
+	const uint32_t B = 1u << pb.shift;
+	const uint32_t blk = blockIdx.x, base = blk << pb.shift;
+	const uint32_t lim = (c.n - base) < B ? (c.n - base) : B;
+	for (uint32_t i = threadIdx.x; i < B; i += blockDim.x) {
+		uint32_t type, dist, len = 1;
+		if (i < lim) pb_decode(b.slab[base + i], base + i, c.n, type, dist, len);
+		lens[i] = (uint16_t)len;
+	}
+	__syncthreads();
+	if (threadIdx.x < MGL_PB_ENTRIES) {
+		uint32_t p = threadIdx.x;
+		while (p < lim) p += lens[p];
+		pb.exits[(size_t)blk * MGL_PB_ENTRIES + threadIdx.x] = (uint16_t)(p - lim);
+	}
+}
+
+#define MGL_PB_STAGE 16u
+__global__ void __launch_bounds__(64) pb_entries(DevCtx c, PBuild pb)
+{
+	__shared__ uint16_t rows[MGL_PB_STAGE * MGL_PB_ENTRIES];
+	const uint32_t lane = threadIdx.x;
+	uint32_t e = 0;
+	for (uint32_t g = 0; g < pb.nblk; g += MGL_PB_STAGE) {
+		const uint32_t cnt = (pb.nblk - g) < MGL_PB_STAGE ? (pb.nblk - g) : MGL_PB_STAGE;
+		for (uint32_t i = lane; i < cnt * MGL_PB_ENTRIES; i += 64) rows[i] = pb.exits[(size_t)g * MGL_PB_ENTRIES + i];
+		wave_sync();
+		if (lane == 0) {
+			for (uint32_t j = 0; j < cnt; j++) {
+				pb.entry[g + j] = ((g + j) << pb.shift) + e;
+				e = rows[j * MGL_PB_ENTRIES + e];
+			}
+		}
+		e = uni(e);
+		wave_sync();
+	}
+	if (lane == 0) pb.entry[pb.nblk] = c.n;
+}
+
+/* ctx_state automaton (lzma_state.c:29-57) as one nibble per source state */
+#define MGL_PB_MAP_ID  0x0000BA9876543210ull
+#define MGL_PB_MAP_LIT 0x0000546543210000ull
+#define MGL_PB_MAP_MATCH 0x0000AAAAA7777777ull
+#define MGL_PB_MAP_SREP 0x0000BBBBB9999999ull
+#define MGL_PB_MAP_LREP 0x0000BBBBB8888888ull
+
+__global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Control* ctl)
+{
+	const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+	if (blk >= pb.nblk) return;
+	uint32_t p = pb.entry[blk];
+	const uint32_t end = ((blk + 1) << pb.shift) < c.n ? ((blk + 1) << pb.shift) : c.n;
+	const uint32_t w_first = blk << (pb.shift - 6), w_lim = (w_first + (1u << (pb.shift - 6))) < b.nw0 ? (w_first + (1u << (pb.shift - 6))) : b.nw0;
+	uint32_t word = w_first;
+	uint64_t on = 0, sp = 0;
+	uint64_t map = MGL_PB_MAP_ID;
+	uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, s0 = 0, s1 = 1, s2 = 2, s3 = 3, npk = 0;
+	bool bad = false;
+	while (p < end) {
+		const uint32_t w = p >> 6;
+		if (w != word) {
+			b.onwalk[word] = on; b.sp0[word] = sp;
+			for (uint32_t z = word + 1; z < w; z++) { b.onwalk[z] = 0; b.sp0[z] = 0; }
+			word = w; on = 0; sp = 0;
+		}
+		const uint64_t bit = 1ull << (p & 63u);
+		on |= bit;
+		uint32_t type, dist, len;
+		if (!pb_decode(b.slab[p], p, c.n, type, dist, len)) bad = true;
+		uint64_t tbl = MGL_PB_MAP_LIT;
+		if (type != MGL_LITERAL) {
+			sp |= bit;
+			tbl = type == MGL_MATCH ? MGL_PB_MAP_MATCH : type == MGL_SHORT_REP ? MGL_PB_MAP_SREP : MGL_PB_MAP_LREP;
+			if (type == MGL_MATCH) {
+				v3 = v2; s3 = s2; v2 = v1; s2 = s1; v1 = v0; s1 = s0;
+				v0 = dist; s0 = 4;
+			} else if (type == MGL_LONG_REP) { /* mgl_advance, including its reading of an index > 3 */
+				const uint32_t tv = dist == 0 ? v0 : dist == 1 ? v1 : dist == 2 ? v2 : v3;
+				const uint32_t ts = dist == 0 ? s0 : dist == 1 ? s1 : dist == 2 ? s2 : s3;
+				if (dist > 2) { v3 = v2; s3 = s2; }
+				if (dist > 1) { v2 = v1; s2 = s1; }
+				if (dist > 0) { v1 = v0; s1 = s0; }
+				v0 = tv; s0 = ts;
+			}
+		}
+		uint64_t r = 0;
+#pragma unroll
+		for (uint32_t i = 0; i < 12; i++) {
+			const uint32_t s = (uint32_t)(map >> (4 * i)) & 15u;
+			r |= ((tbl >> (4 * s)) & 15ull) << (4 * i);
+		}
+		map = r;
+		p += len;
+		npk++;
+	}
+	if (word < w_lim) {
+		b.onwalk[word] = on; b.sp0[word] = sp;
+		for (uint32_t z = word + 1; z < w_lim; z++) { b.onwalk[z] = 0; b.sp0[z] = 0; }
+	}
+	pb.tf_ctx[blk] = map;
+	uint32_t* t = pb.tf_dist + (size_t)blk * 8;
+	t[0] = v0; t[1] = v1; t[2] = v2; t[3] = v3; t[4] = s0; t[5] = s1; t[6] = s2; t[7] = s3;
+	pb.tf_pk[blk] = npk;
+	if (bad) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
+}
+
+/* A block's effect on the walk state: ctx_state map (12 nibbles) and where each rep distance comes from */
+struct PbTf {
+	uint64_t map;
+	uint32_t v0, v1, v2, v3, s0, s1, s2, s3;
+};
+__device__ __forceinline__ PbTf pb_tf_load(const PBuild& pb, uint32_t blk)
+{
+	PbTf t;
+	t.map = pb.tf_ctx[blk];
+	const uint4 tv = ((const uint4*)pb.tf_dist)[(size_t)blk * 2], ts = ((const uint4*)pb.tf_dist)[(size_t)blk * 2 + 1];
+	t.v0 = tv.x; t.v1 = tv.y; t.v2 = tv.z; t.v3 = tv.w; t.s0 = ts.x; t.s1 = ts.y; t.s2 = ts.z; t.s3 = ts.w;
+	return t;
+}
+/* state after the block, given the state before it */
+__device__ __forceinline__ void pb_tf_apply(const PbTf& t, uint32_t& cs, uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3)
+{
+#define PB_PICK(q, a) ((q) == 4u ? (a) : (q) == 0u ? d0 : (q) == 1u ? d1 : (q) == 2u ? d2 : d3)
+	const uint32_t n0 = PB_PICK(t.s0, t.v0), n1 = PB_PICK(t.s1, t.v1), n2 = PB_PICK(t.s2, t.v2), n3 = PB_PICK(t.s3, t.v3);
+#undef PB_PICK
+	d0 = n0; d1 = n1; d2 = n2; d3 = n3;
+	cs = (uint32_t)(t.map >> (4 * cs)) & 15u;
+}
+/* a := a followed by t */
+__device__ __forceinline__ void pb_tf_then(PbTf& a, const PbTf& t)
+{
+	uint64_t r = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 12; i++) {
+		const uint32_t s = (uint32_t)(a.map >> (4 * i)) & 15u;
+		r |= ((t.map >> (4 * s)) & 15ull) << (4 * i);
+	}
+	a.map = r;
+#define PB_SRC_V(q, cv) ((q) == 4u ? (cv) : (q) == 0u ? a.v0 : (q) == 1u ? a.v1 : (q) == 2u ? a.v2 : a.v3)
+#define PB_SRC_S(q) ((q) == 4u ? 4u : (q) == 0u ? a.s0 : (q) == 1u ? a.s1 : (q) == 2u ? a.s2 : a.s3)
+	const uint32_t nv0 = PB_SRC_V(t.s0, t.v0), nv1 = PB_SRC_V(t.s1, t.v1), nv2 = PB_SRC_V(t.s2, t.v2), nv3 = PB_SRC_V(t.s3, t.v3);
+	const uint32_t ns0 = PB_SRC_S(t.s0), ns1 = PB_SRC_S(t.s1), ns2 = PB_SRC_S(t.s2), ns3 = PB_SRC_S(t.s3);
+#undef PB_SRC_V
+#undef PB_SRC_S
+	a.v0 = nv0; a.v1 = nv1; a.v2 = nv2; a.v3 = nv3; a.s0 = ns0; a.s1 = ns1; a.s2 = ns2; a.s3 = ns3;
+}
+
+/* 4096 blocks per round: every lane composes its 64 consecutive blocks, the 64 lane totals are
+ * applied in order (uniform), then every lane replays its blocks from its own entry state */
+__global__ void __launch_bounds__(64) pb_scan(PBuild pb)
+{
+	const uint32_t lane = threadIdx.x;
+	uint32_t cs = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0; /* uniform running state */
+	unsigned long long packets = 0;
+	for (uint32_t g = 0; g < pb.nblk; g += 4096) {
+		const uint32_t first = g + lane * 64u;
+		const uint32_t last = (first + 64u) < pb.nblk ? (first + 64u) : pb.nblk;
+		PbTf acc;
+		acc.map = MGL_PB_MAP_ID; acc.v0 = acc.v1 = acc.v2 = acc.v3 = 0; acc.s0 = 0; acc.s1 = 1; acc.s2 = 2; acc.s3 = 3;
+		for (uint32_t blk = first; blk < last; blk++) {
+			const PbTf t = pb_tf_load(pb, blk);
+			pb_tf_then(acc, t);
+			packets += pb.tf_pk[blk];
+		}
+		uint32_t my_cs = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+		for (uint32_t j = 0; j < 64; j++) {
+			if (lane == j) { my_cs = cs; m0 = d0; m1 = d1; m2 = d2; m3 = d3; }
+			PbTf t;
+			t.map = rdlane64(acc.map, j);
+			t.v0 = rdlane(acc.v0, j); t.v1 = rdlane(acc.v1, j); t.v2 = rdlane(acc.v2, j); t.v3 = rdlane(acc.v3, j);
+			t.s0 = rdlane(acc.s0, j); t.s1 = rdlane(acc.s1, j); t.s2 = rdlane(acc.s2, j); t.s3 = rdlane(acc.s3, j);
+			pb_tf_apply(t, cs, d0, d1, d2, d3);
+		}
+		for (uint32_t blk = first; blk < last; blk++) {
+			uint4* o = (uint4*)(pb.st_in + (size_t)blk * 8);
+			o[0] = make_uint4(my_cs, m0, m1, m2);
+			o[1] = make_uint4(m3, 0, 0, 0);
+			const PbTf t = pb_tf_load(pb, blk);
+			pb_tf_apply(t, my_cs, m0, m1, m2, m3);
+		}
+	}
+	packets = wave_sum64(packets);
+	if (lane == 0) {
+		pb.acc[0] = 0;
+		pb.acc[1] = packets;
+		pb.acc[2] = cs; pb.acc[3] = d0; pb.acc[4] = d1; pb.acc[5] = d2; pb.acc[6] = d3; pb.acc[7] = 0;
+	}
+}
+
+/* level[w >> 6] bit (w & 63) = lower[w] != 0; the lower array is zero padded to a multiple of 64 words */
+__global__ void __launch_bounds__(256) pb_levels(const uint64_t* lower, uint64_t* level, uint32_t nlower, uint32_t nlevel)
+{
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	const unsigned long long m = __ballot(w < nlower && lower[w] != 0);
+	if ((threadIdx.x & 63u) == 0 && (w >> 6) < nlevel) level[w >> 6] = m;
+}
+
+/* One wavefront walks one block from its entry state.  SCATTER = false: special-state records +
+ * events per context (pb.hist row) + direct-bit cost.  SCATTER = true: events into the chains. */
+template <bool SCATTER>
+__global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t* cnt = (uint32_t*)smem;
+	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+	uint32_t* row = pb.hist + (size_t)blk * b.ck_elems;
+	if (SCATTER && *b.pool_top > b.pool_cap) return;
+	for (uint32_t i = lane; i < b.ck_elems; i += 64) cnt[i] = SCATTER ? (i < c.L.total ? b.ch_off[i] + row[i] : 0u) : 0u;
+	wave_sync();
+	Walk w;
+	walk_reset(w);
+	{
+		const uint32_t* s = pb.st_in + (size_t)blk * 8;
+		w.st.pos = pb.entry[blk];
+		w.st.ctx_state = s[0];
+		w.st.dists[0] = s[1]; w.st.dists[1] = s[2]; w.st.dists[2] = s[3]; w.st.dists[3] = s[4];
+	}
+	const uint32_t end = ((blk + 1) << pb.shift) < c.n ? ((blk + 1) << pb.shift) : c.n;
+	uint32_t ndirect = 0;
+	while (w.st.pos < end) {
+		const uint32_t pos = w.st.pos;
+		walk_window(w, c, b.slab, lane);
+		uint32_t type, dist, len;
+		pb_decode(walk_slab_at(w, pos), pos, c.n, type, dist, len);
+		if (!SCATTER && type != MGL_LITERAL && lane < 8) {
+			const uint32_t v = lane == 0 ? w.st.ctx_state : lane == 1 ? w.st.dists[0] : lane == 2 ? w.st.dists[1]
+			                 : lane == 3 ? w.st.dists[2] : lane == 4 ? w.st.dists[3] : 0u;
+			b.sp_state[(size_t)pos * 8 + lane] = v;
+		}
+		const uint32_t byte = walk_byte_at(w, pos);
+		uint32_t match_byte = 0, prev_byte = 0;
+		if (type == MGL_LITERAL) {
+			if (w.st.ctx_state >= 7 && w.st.dists[0] < pos) match_byte = c.data[pos - w.st.dists[0] - 1];
+			if (c.L.lc > 0 && pos > 0) prev_byte = c.data[pos - 1];
+		}
+		mgl_plan pl;
+		mgl_plan_packet(&c.L, &w.st, type, dist, len, byte, match_byte, prev_byte, &pl);
+		if (lane < pl.nev) {
+			uint32_t ctx, bit;
+			mgl_plan_event(&pl, lane, &ctx, &bit);
+			const uint32_t k = cnt[ctx]++; /* contexts of one packet are distinct: no conflict */
+			if (SCATTER) {
+				b.ch_pos[k] = pos;
+				b.ch_ev[k] = (uint16_t)(bit << 15);
+			}
+		}
+		ndirect += pl.ndirect;
+		mgl_advance(&w.st, type, dist, len);
+	}
+	if (!SCATTER) {
+		wave_sync();
+		for (uint32_t i = lane; i < b.ck_elems; i += 64) row[i] = cnt[i];
+		if (lane == 0 && ndirect) atomicAdd(&pb.acc[0], (unsigned long long)ndirect << 11);
+	}
+}
+
+/* per context: counts per block -> offset of the block's first event in the context's chain */
+__global__ void __launch_bounds__(256) pb_offsets(Base2 b, PBuild pb, uint32_t total)
+{
+	const uint32_t ctx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ctx >= b.ck_elems) return;
+	uint32_t run = 0;
+	uint32_t* col = pb.hist + ctx;
+	const size_t E = b.ck_elems;
+	uint32_t blk = 0;
+	for (; blk + 8 <= pb.nblk; blk += 8) {
+		uint32_t t[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) t[u] = col[(size_t)(blk + u) * E];
+#pragma unroll
+		for (int u = 0; u < 8; u++) { col[(size_t)(blk + u) * E] = run; run += t[u]; }
+	}
+	for (; blk < pb.nblk; blk++) { const uint32_t t = col[(size_t)blk * E]; col[(size_t)blk * E] = run; run += t; }
+	if (ctx < total) b.ch_len[ctx] = run;
+}
+
+/* chain offsets; capacity = 2 len + 257 rounded up to 8 entries, as in k_build */
+__device__ __forceinline__ uint32_t pb_nseg(uint32_t len) { return len ? (len + MGL_PB_SEG - 1u) / MGL_PB_SEG : 1u; }
+__global__ void __launch_bounds__(64) pb_layout(Base2 b, PBuild pb, Control* ctl, uint32_t total)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t per = (total + 63u) / 64u;
+	const uint32_t lo = lane * per, hi = (lo + per) < total ? (lo + per) : total;
+	uint32_t sum = 0, ssum = 0;
+	for (uint32_t i = lo; i < hi; i++) { sum += (2u * b.ch_len[i] + 257u + 7u) & ~7u; ssum += pb_nseg(b.ch_len[i]); }
+	uint32_t incl = sum, sincl = ssum;
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+		const uint32_t u = (uint32_t)__shfl_up((int)sincl, o, 64);
+		if ((int)lane >= o) { incl += t; sincl += u; }
+	}
+	uint32_t run = incl - sum, srun = sincl - ssum;
+	for (uint32_t i = lo; i < hi; i++) {
+		const uint32_t cap = (2u * b.ch_len[i] + 257u + 7u) & ~7u;
+		b.ch_off[i] = run; b.ch_cap[i] = cap;
+		run += cap;
+		pb.seg_off[i] = srun;
+		srun += pb_nseg(b.ch_len[i]);
+	}
+	if (lane == 63) pb.seg_off[total] = sincl;
+	const uint32_t all = (uint32_t)__shfl((int)incl, 63, 64);
+	if (lane == 0) {
+		*b.pool_top = all;
+		if (all > b.pool_cap) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
+	}
+}
+
+/* The probability before every event of every chain, the sentinels, the cost.  A chain is cut into
+ * segments of MGL_PB_SEG events, one thread each.  The update v -= v >> 5 / v += (2048 - v) >> 5 is
+ * monotone in v, so running both ends of the reachable range (31 and 2017) through the
+ * MGL_PB_WARM events before a segment brackets the true value; when the two meet -- they nearly
+ * always do within a few hundred events -- the value at the segment start is exact without the
+ * chain's history.  Segments where they have not met are left to pb_sim_fix. */
+__device__ __forceinline__ void pb_sim_range(uint16_t* ev, uint32_t i0, uint32_t i1, uint32_t& p, unsigned long long& cost, const uint16_t* T)
+{
+	for (uint32_t i = i0; i < i1; i += 8) { /* chains are 16-byte aligned, i0 is a multiple of 8 */
+		uint4 v = *(const uint4*)(ev + i);
+		uint32_t wds[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) {
+			if (i + k < i1) {
+				const uint32_t e = (wds[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+				const uint32_t bit = e >> 15;
+				wds[k >> 1] = (wds[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | (((bit << 15) | p) << (16 * (k & 1)));
+				cost += T[bit ? 2048u - p : p];
+				p = mgl_prob_update(p, bit);
+			}
+		}
+		*(uint4*)(ev + i) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+	}
+}
+__global__ void __launch_bounds__(64) pb_sim(DevCtx c, Base2 b, PBuild pb)
+{
+	__shared__ uint16_t T[2048];
+	for (uint32_t i = threadIdx.x; i < 2048; i += 64) T[i] = c.cost_tbl[i];
+	__syncthreads();
+	if (*b.pool_top > b.pool_cap) return;
+	const uint32_t total = c.L.total;
+	const uint32_t seg = blockIdx.x * 64 + threadIdx.x;
+	unsigned long long cost = 0;
+	if (seg < pb.seg_off[total] && seg < pb.seg_cap) {
+		uint32_t lo = 0, hi = total; /* last context with seg_off <= seg */
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (pb.seg_off[mid] <= seg) lo = mid; else hi = mid;
+		}
+		const uint32_t ctx = lo, s = seg - pb.seg_off[ctx];
+		const uint32_t off = b.ch_off[ctx], len = b.ch_len[ctx];
+		uint16_t* ev = b.ch_ev + off;
+		const uint32_t i0 = s * MGL_PB_SEG, i1 = (i0 + MGL_PB_SEG) < len ? (i0 + MGL_PB_SEG) : len;
+		uint32_t p = MGL_PROB_INIT;
+		bool ok = true;
+		if (i0 != 0) {
+			uint32_t plo = 31u, phi = 2017u;
+			for (uint32_t i = i0 - MGL_PB_WARM; i < i0; i += 8) {
+				const uint4 v = *(const uint4*)(ev + i);
+				const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for (uint32_t k = 0; k < 8; k++) {
+					const uint32_t bit = (wds[k >> 1] >> (16 * (k & 1) + 15)) & 1u;
+					plo = mgl_prob_update(plo, bit);
+					phi = mgl_prob_update(phi, bit);
+				}
+			}
+			ok = plo == phi && !pb.force_fix;
+			p = plo;
+		}
+		pb.unres[seg] = ok ? 0 : 1;
+		if (ok) {
+			pb_sim_range(ev, i0, i1, p, cost, T);
+			if (i1 == len) { ev[len] = (uint16_t)p; b.ch_pos[off + len] = MGL_POS_INF; }
+		}
+	}
+	cost = wave_sum64(cost);
+	if (threadIdx.x == 0 && cost) atomicAdd(&pb.acc[0], cost);
+}
+/* the segments pb_sim could not start: in chain order, from the entry before them */
+__global__ void __launch_bounds__(64) pb_sim_fix(DevCtx c, Base2 b, PBuild pb)
+{
+	__shared__ uint16_t T[2048];
+	for (uint32_t i = threadIdx.x; i < 2048; i += 64) T[i] = c.cost_tbl[i];
+	__syncthreads();
+	if (*b.pool_top > b.pool_cap) return;
+	const uint32_t ctx = blockIdx.x * 64 + threadIdx.x;
+	unsigned long long cost = 0, redone = 0;
+	if (ctx < c.L.total) {
+		const uint32_t s0 = pb.seg_off[ctx], s1 = pb.seg_off[ctx + 1];
+		const uint32_t off = b.ch_off[ctx], len = b.ch_len[ctx];
+		uint16_t* ev = b.ch_ev + off;
+		for (uint32_t sg = s0 + 1; sg < s1 && sg < pb.seg_cap; sg++) {
+			if (!pb.unres[sg]) continue;
+			const uint32_t i0 = (sg - s0) * MGL_PB_SEG, i1 = (i0 + MGL_PB_SEG) < len ? (i0 + MGL_PB_SEG) : len;
+			const uint32_t e = ev[i0 - 1];
+			uint32_t p = mgl_prob_update(e & 0x7FFFu, e >> 15);
+			pb_sim_range(ev, i0, i1, p, cost, T);
+			if (i1 == len) { ev[len] = (uint16_t)p; b.ch_pos[off + len] = MGL_POS_INF; }
+			redone++;
+		}
+	}
+	cost = wave_sum64(cost);
+	redone = wave_sum64(redone);
+	if (threadIdx.x == 0 && cost) atomicAdd(&pb.acc[0], cost);
+	if (threadIdx.x == 0 && redone) atomicAdd(&pb.acc[7], redone);
+}
+
+/* dense checkpoints: row k = every context's probability before the first packet at or after
+ * 64 k = the value stored with the context's first chain entry at a position >= 64 k (the
+ * sentinel holds the final value).  Lane = context; rows leave through LDS as 128-byte stores. */
+__global__ void __launch_bounds__(64) pb_ckpt(DevCtx c, Base2 b)
+{
+	__shared__ uint16_t tile[MGL_PB_CK_ROWS * 64];
+	if (*b.pool_top > b.pool_cap) return;
+	const uint32_t lane = threadIdx.x, ctx = blockIdx.x * 64 + lane;
+	const uint32_t k0 = blockIdx.y * MGL_PB_CK_ROWS, k1 = (k0 + MGL_PB_CK_ROWS) < b.nck ? (k0 + MGL_PB_CK_ROWS) : b.nck;
+	if (ctx < c.L.total) {
+		const uint32_t off = b.ch_off[ctx], len = b.ch_len[ctx];
+		const uint32_t* cp = b.ch_pos + off;
+		const uint16_t* ce = b.ch_ev + off;
+		uint32_t lo = 0, hi = len; /* first entry with position >= 64 k0 (len = the sentinel) */
+		const uint32_t want = k0 << MGL_CK2_SHIFT;
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (cp[mid] < want) lo = mid + 1; else hi = mid;
+		}
+		uint32_t idx = lo, pos = cp[idx];
+		for (uint32_t k = k0; k < k1; k++) {
+			const uint32_t at = k << MGL_CK2_SHIFT;
+			if (pos < at) {
+				/* positions in a chain are strictly increasing and pos >= at - 64: the entry wanted is
+				 * at most 64 further on (or the sentinel) */
+				uint32_t a = idx + 1, z = (idx + (1u << MGL_CK2_SHIFT)) < len ? (idx + (1u << MGL_CK2_SHIFT)) : len;
+				while (a < z) {
+					const uint32_t mid = (a + z) >> 1;
+					if (cp[mid] < at) a = mid + 1; else z = mid;
+				}
+				idx = a; pos = cp[idx];
+			}
+			tile[(k - k0) * 64 + lane] = ce[idx] & 0x7FFFu;
+		}
+	} else {
+		for (uint32_t k = k0; k < k1; k++) tile[(k - k0) * 64 + lane] = MGL_PROB_INIT;
+	}
+	__syncthreads();
+	if (ctx < b.ck_elems)
+		for (uint32_t k = k0; k < k1; k++) b.ck_probs[(size_t)k * b.ck_elems + ctx] = tile[(k - k0) * 64 + lane];
+}
+
+__global__ void pb_finish(PBuild pb, Control* ctl)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	ctl->packets = pb.acc[1];
+	ctl->rebuild_cost = pb.acc[0];
+	ctl->final_ctx_state = (uint32_t)pb.acc[2];
+	for (int i = 0; i < 4; i++) ctl->final_dists[i] = (uint32_t)pb.acc[3 + i];
+}

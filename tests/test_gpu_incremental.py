@@ -86,11 +86,12 @@ def check_base(sa, o, slab, data):
             ei += 1
 
 
+@pytest.mark.parametrize("serial_build", [False, True], ids=["parallel_build", "serial_build"])
 @pytest.mark.parametrize("name", ["lorem4k", "enwik3k", "reps", "zeros600"])
-def test_base_structures_match_oracle_trace(name, golden, golden_input):
+def test_base_structures_match_oracle_trace(name, serial_build, golden, golden_input):
     data = golden_input(name)
     n = len(data)
-    sa = binding.SA(data, neighbours_per_step=8)
+    sa = binding.SA(data, neighbours_per_step=8, serial_build=serial_build)
     o = Oracle(data)
     slabs = [literal_slab(n)]
     if name in golden["evolved_walks"]:
@@ -219,3 +220,51 @@ def test_epoch_snapshots_equal_rebuild(name, K, golden, golden_input):
     assert st["evaluations"] > 0
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("cfg,size,K,steps", [("c2", 100000, 1024, 40), ("c5", 70000, 256, 30), ("c2", 5000, 64, 60), ("c2", 1025, 32, 20)])
+def test_parallel_build_equals_serial_build(cfg, size, K, steps):
+    """mgl_pbuild.hip (block-parallel) and k_build (one wavefront) derive identical structures,
+    totals and final walk state -- all-literal and SA-evolved slabs, pb = 0 and 2, sizes that end
+    inside a block and one byte into a new one."""
+    data, _ = corpus.config_input(cfg, size)
+    props = dict(pb=2, max_bucket_scan=512) if cfg == "c5" else {}
+    par = binding.SA(data, neighbours_per_step=K, seed=3, **props)
+    ser = binding.SA(data, neighbours_per_step=8, seed=3, serial_build=True, snapshots=False, **props)
+    o = Oracle(data, dict_limit=0x400000, **({"pb": 2} if cfg == "c5" else {}))
+    for round_ in range(2):
+        cur, cost = par.current()
+        ser.set_slab(cur)
+        cur2, cost2 = ser.current()
+        assert cost == cost2 and (cur == cur2).all()
+        if size <= 5000 or round_ == 0:
+            assert cost == o.cost_slab(cur.astype(literal_slab(1).dtype))["total"]
+        par.set_slab(cur)  # rebuild `par` from scratch through the parallel builder
+        cur3, cost3 = par.current()
+        assert cost3 == cost
+        assert_same_base(canonical_base(par, cur), canonical_base(ser, cur), (cfg, size, round_))
+        par.run(steps)
+    par.close()
+    ser.close()
+
+
+def test_parallel_build_serial_segment_path():
+    """pb_sim starts a chain segment from a warm-up that brackets the probability; pb_sim_fix redoes
+    the segments whose bracket did not close.  That never happens on these inputs, so force it
+    (mgl_debug_set key 1) and require the same structures and cost."""
+    data, _ = corpus.config_input("c2", 60000)
+    a = binding.SA(data, neighbours_per_step=512, seed=9)
+    a.run(30)
+    cur, cost = a.current()
+    want = canonical_base(a, cur)
+    a.L.mgl_debug_set(a.h, 1, 1)
+    a.set_slab(cur)
+    acc = a.debug_dump(11, np.uint64)
+    assert int(acc[7]) > 10  # segments redone serially
+    cur2, cost2 = a.current()
+    assert cost2 == cost and (cur2 == cur).all()
+    assert_same_base(canonical_base(a, cur), want, "forced pb_sim_fix")
+    a.L.mgl_debug_set(a.h, 1, 0)
+    a.set_slab(cur)
+    assert int(a.debug_dump(11, np.uint64)[7]) == 0
+    a.close()

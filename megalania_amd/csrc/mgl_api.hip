@@ -6,6 +6,7 @@
 #include "mgl_kernels2.hip"
 #include "mgl_kernels3.hip"
 #include "mgl_pbuild.hip"
+#include "mgl_index.hip"
 #include "../../include/megalania_hip.h"
 
 #include <math.h>
@@ -341,18 +342,32 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMemset(sa->d_data, 0, n + 128));
 	HIPCHK(hipMemcpy(sa->d_data, data, n, hipMemcpyHostToDevice));
 
-	/* match index (substring_enumerator.c:26-47): positions bucketed by leading bigram,
-	 * ascending inside a bucket.  Setup work, built once on the host. */
+	/* match index (substring_enumerator.c:26-47): positions bucketed by leading bigram, ascending
+	 * inside a bucket -- a stable two-pass counting sort on the device (mgl_index.hip) */
 	{
-		std::vector<uint32_t> off(65537, 0), posv(n ? n : 1, 0);
-		for (size_t i = 1; i < n; i++) off[(((uint32_t)data[i - 1] << 8) | data[i]) + 1]++;
-		for (uint32_t b = 0; b < 65536; b++) off[b + 1] += off[b];
-		std::vector<uint32_t> fill(off.begin(), off.end() - 1);
-		for (size_t i = 1; i < n; i++) posv[fill[((uint32_t)data[i - 1] << 8) | data[i]]++] = (uint32_t)(i - 1);
+		const uint32_t m = (uint32_t)(n - 1); /* positions that start a bigram */
 		HIPCHK(hipMalloc(&sa->d_bucket_off, sizeof(uint32_t) * 65537));
-		HIPCHK(hipMalloc(&sa->d_bucket_pos, sizeof(uint32_t) * posv.size()));
-		HIPCHK(hipMemcpy(sa->d_bucket_off, off.data(), sizeof(uint32_t) * 65537, hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(sa->d_bucket_pos, posv.data(), sizeof(uint32_t) * posv.size(), hipMemcpyHostToDevice));
+		HIPCHK(hipMalloc(&sa->d_bucket_pos, sizeof(uint32_t) * (n ? n : 1)));
+		if (m == 0) HIPCHK(hipMemset(sa->d_bucket_off, 0, sizeof(uint32_t) * 65537));
+		else {
+			const uint32_t nblk = (m + MGL_IX_ITEMS - 1) / MGL_IX_ITEMS;
+			uint32_t *tmp = nullptr, *matrix = nullptr;
+			HIPCHK(hipMalloc(&tmp, sizeof(uint32_t) * m));
+			HIPCHK(hipMalloc(&matrix, sizeof(uint32_t) * 256 * (size_t)nblk));
+			for (int pass = 0; pass < 2; pass++) {
+				const uint32_t* in = pass == 0 ? nullptr : tmp;
+				uint32_t* out = pass == 0 ? tmp : sa->d_bucket_pos;
+				hipLaunchKernelGGL(ix_count, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, m, pass, matrix, nblk);
+				hipLaunchKernelGGL(ix_scan, dim3(1), dim3(1024), 0, sa->stream, matrix, 256u * nblk);
+				hipLaunchKernelGGL(ix_scatter, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, out, m, pass,
+				                   (const uint32_t*)matrix, nblk);
+			}
+			hipLaunchKernelGGL(ix_offsets, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
+			                   (const uint32_t*)sa->d_bucket_pos, m, sa->d_bucket_off);
+			hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(sa->stream);
+			(void)hipFree(tmp); (void)hipFree(matrix);
+			HIPCHK(e1); HIPCHK(e2);
+		}
 	}
 	HIPCHK(hipMalloc(&sa->d_cost_tbl, sizeof(k_cost_table)));
 	HIPCHK(hipMemcpy(sa->d_cost_tbl, k_cost_table, sizeof(k_cost_table), hipMemcpyHostToDevice));
@@ -885,6 +900,8 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
 	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
+	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
+	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
 	}

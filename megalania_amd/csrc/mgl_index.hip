@@ -1,0 +1,108 @@
+/*
+ * mgl_index.hip -- the match index built on the device.
+ *
+ * substring_enumerator.c:26-47 buckets every position by its leading bigram and keeps the
+ * positions of a bucket ascending.  Here: a stable two-pass counting sort of the positions
+ * 0 .. n-2, first by data[pos + 1], then by data[pos] (LSD radix, 8 bits per pass).  A pass is
+ * three kernels over blocks of 4096 items: per-block digit histogram, one exclusive scan of the
+ * digit-major histogram matrix, and a scatter in which a wavefront ranks its 64 items among equal
+ * digits with ballots, so equal keys keep their position order.  bucket_off is then read off the
+ * sorted keys.  The dictionary window (dict_limit) is applied at query time by a search inside
+ * the bucket (bucket_lower_bound, mgl_kernels.hip), so the index itself is window-independent.
+ */
+#include "mgl_device.h"
+
+#define MGL_IX_ITEMS 4096u /* per wavefront */
+
+__device__ __forceinline__ uint32_t ix_digit(const uint8_t* data, const uint32_t* in, uint32_t idx, int pass, uint32_t& pos)
+{
+	pos = pass == 0 ? idx : in[idx];
+	return pass == 0 ? data[pos + 1] : data[pos];
+}
+
+__global__ void __launch_bounds__(64) ix_count(const uint8_t* data, const uint32_t* in, uint32_t m, int pass, uint32_t* matrix, uint32_t nblk)
+{
+	__shared__ uint32_t cnt[256];
+	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+	for (uint32_t i = lane; i < 256; i += 64) cnt[i] = 0;
+	__syncthreads();
+	const uint32_t lo = blk * MGL_IX_ITEMS, hi = (lo + MGL_IX_ITEMS) < m ? (lo + MGL_IX_ITEMS) : m;
+	for (uint32_t idx = lo + lane; idx < hi; idx += 64) {
+		uint32_t pos;
+		atomicAdd(&cnt[ix_digit(data, in, idx, pass, pos)], 1u);
+	}
+	__syncthreads();
+	for (uint32_t i = lane; i < 256; i += 64) matrix[(size_t)i * nblk + blk] = cnt[i];
+}
+
+/* in-place exclusive scan of `count` words by one workgroup */
+__global__ void __launch_bounds__(1024) ix_scan(uint32_t* a, uint32_t count)
+{
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t carry_s;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	if (tid == 0) carry_s = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < count; base += 4096) {
+		const uint32_t i0 = base + tid * 4;
+		uint32_t v[4], s = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { v[k] = (i0 + k) < count ? a[i0 + k] : 0u; s += v[k]; }
+		uint32_t incl = s;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+			if ((int)lane >= o) incl += t;
+		}
+		if (lane == 63) wsum[wv] = incl;
+		__syncthreads();
+		uint32_t before = carry_s;
+		for (uint32_t w = 0; w < wv; w++) before += wsum[w];
+		uint32_t run = before + incl - s;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { if ((i0 + k) < count) a[i0 + k] = run; run += v[k]; }
+		__syncthreads();
+		if (tid == 1023) carry_s = run;
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(64) ix_scatter(const uint8_t* data, const uint32_t* in, uint32_t* out, uint32_t m, int pass,
+                                                 const uint32_t* matrix, uint32_t nblk)
+{
+	__shared__ uint32_t cnt[256];
+	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
+	for (uint32_t i = lane; i < 256; i += 64) cnt[i] = matrix[(size_t)i * nblk + blk];
+	wave_sync();
+	const uint32_t lo = blk * MGL_IX_ITEMS;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	for (uint32_t it = 0; it < MGL_IX_ITEMS / 64u; it++) {
+		const uint32_t idx = lo + it * 64u + lane;
+		const bool valid = idx < m;
+		if (!__any(valid)) break;
+		uint32_t pos = 0;
+		const uint32_t digit = valid ? ix_digit(data, in, idx, pass, pos) : 0u;
+		unsigned long long peers = __ballot(valid);
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) {
+			const bool bit = (digit >> k) & 1u;
+			const unsigned long long bm = __ballot(bit);
+			peers &= bit ? bm : ~bm;
+		}
+		const uint32_t rank = (uint32_t)__popcll(peers & below);
+		const uint32_t base = valid ? cnt[digit] : 0u;
+		wave_sync();
+		if (valid && rank == 0) cnt[digit] = base + (uint32_t)__popcll(peers);
+		wave_sync();
+		if (valid) out[base + rank] = pos;
+	}
+}
+
+/* bucket_off[key] = first sorted index whose key is >= key; bucket_off[65536] = m */
+__global__ void __launch_bounds__(256) ix_offsets(const uint8_t* data, const uint32_t* sorted, uint32_t m, uint32_t* bucket_off)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > m) return;
+	const uint32_t key = j < m ? (((uint32_t)data[sorted[j]] << 8) | data[sorted[j] + 1]) : 65536u;
+	const uint32_t prev = j == 0 ? 0u : ((((uint32_t)data[sorted[j - 1]] << 8) | data[sorted[j - 1] + 1]) + 1u);
+	for (uint32_t k = prev; k <= key; k++) bucket_off[k] = j; /* empty buckets in between start here too */
+}

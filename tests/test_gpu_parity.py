@@ -240,3 +240,20 @@ def test_pb2_elf_shaped_properties():
     stream = binding.emit_stream(data, cur, pb=2)
     assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
     sa.close()
+
+
+@pytest.mark.parametrize("cfg,size", [("c2", 100000), ("c5", 200000), ("c1", 4096), ("c2", 4097), ("c2", 2), ("c2", 3)])
+def test_match_index_built_on_device(cfg, size):
+    """substring_enumerator.c:26-47: positions bucketed by leading bigram, ascending inside a
+    bucket.  The device builds it with a stable two-pass counting sort (mgl_index.hip)."""
+    data, _ = corpus.config_input(cfg, size)
+    sa = binding.SA(data, neighbours_per_step=8)
+    d = np.frombuffer(data, dtype=np.uint8).astype(np.uint32)
+    keys = (d[:-1] << 8) | d[1:]
+    want_pos = np.argsort(keys, kind="stable").astype(np.uint32)
+    want_off = np.searchsorted(keys[want_pos], np.arange(65537), side="left").astype(np.uint32)
+    got_off = sa.debug_dump(12, np.uint32)
+    got_pos = sa.debug_dump(13, np.uint32)
+    assert (got_off == want_off).all()
+    assert (got_pos == want_pos).all()
+    sa.close()

@@ -61,6 +61,7 @@ struct mgl_sa {
 	uint8_t* d_data;
 	uint32_t* d_bucket_off;
 	uint32_t* d_bucket_pos;
+	uint16_t* d_bucket_nx;
 	uint16_t* d_cost_tbl;
 	BaseMem base, scratch;
 	mgl_pk* d_best;
@@ -305,7 +306,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	if (!sa) return;
 	(void)hipSetDevice(sa->device);
 	if (sa->stream) (void)hipStreamSynchronize(sa->stream);
-	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_cost_tbl);
+	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_bucket_nx); dfree(sa->d_cost_tbl);
 	free_base(sa->base); free_base(sa->scratch);
 	dfree(sa->d_best);
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
@@ -348,6 +349,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		const uint32_t m = (uint32_t)(n - 1); /* positions that start a bigram */
 		HIPCHK(hipMalloc(&sa->d_bucket_off, sizeof(uint32_t) * 65537));
 		HIPCHK(hipMalloc(&sa->d_bucket_pos, sizeof(uint32_t) * (n ? n : 1)));
+		HIPCHK(hipMalloc(&sa->d_bucket_nx, sizeof(uint16_t) * (n ? n : 1)));
 		if (m == 0) HIPCHK(hipMemset(sa->d_bucket_off, 0, sizeof(uint32_t) * 65537));
 		else {
 			const uint32_t nblk = (m + MGL_IX_ITEMS - 1) / MGL_IX_ITEMS;
@@ -364,6 +366,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			}
 			hipLaunchKernelGGL(ix_offsets, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
 			                   (const uint32_t*)sa->d_bucket_pos, m, sa->d_bucket_off);
+			hipLaunchKernelGGL(ix_next2, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
+			                   (const uint32_t*)sa->d_bucket_pos, m, sa->d_bucket_nx);
 			hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(sa->stream);
 			(void)hipFree(tmp); (void)hipFree(matrix);
 			HIPCHK(e1); HIPCHK(e2);
@@ -373,7 +377,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMemcpy(sa->d_cost_tbl, k_cost_table, sizeof(k_cost_table), hipMemcpyHostToDevice));
 
 	sa->ctx.data = sa->d_data; sa->ctx.n = (uint32_t)n;
-	sa->ctx.bucket_off = sa->d_bucket_off; sa->ctx.bucket_pos = sa->d_bucket_pos;
+	sa->ctx.bucket_off = sa->d_bucket_off; sa->ctx.bucket_pos = sa->d_bucket_pos; sa->ctx.bucket_nx = sa->d_bucket_nx;
 	sa->ctx.cost_tbl = sa->d_cost_tbl; sa->ctx.L = L;
 	sa->ctx.dict_limit = sa->cfg.dict_limit; sa->ctx.max_scan = sa->cfg.max_bucket_scan; sa->ctx.top_k = sa->cfg.top_k;
 

@@ -20,7 +20,7 @@
 #define MGL_CKPT_SHIFT 10u          /* one prefix checkpoint per 1024 input bytes */
 #define MGL_MAX_DIFFS 64u           /* journal capacity per neighbour */
 #define MGL_MAX_TOPK 32u
-#define MGL_PRICE_WORDS 944u          /* top-K price tables per wavefront (u32): 2x272 lengths, 4x64 slots, 128 tails, 16 align */
+#define MGL_PRICE_WORDS 1008u         /* top-K price tables per wavefront (u32): 2x272 lengths, 4x64 slots, 128 tails, 16 align, 64 slot bounds */
 #define MGL_SEQ_MASK ((1ull << 44) - 1ull)
 #define MGL_INVALID_COST (~0ull)
 
@@ -29,6 +29,7 @@ struct DevCtx {
 	uint32_t n;
 	const uint32_t* bucket_off; /* 65537 */
 	const uint32_t* bucket_pos; /* n-1 positions, ascending inside each bigram bucket */
+	const uint16_t* bucket_nx;  /* per entry of bucket_pos: data[p + 2] | data[p + 3] << 8 */
 	const uint16_t* cost_tbl;   /* 2048 x u16 */
 	mgl_layout L;
 	uint32_t dict_limit;

@@ -106,3 +106,12 @@ __global__ void __launch_bounds__(256) ix_offsets(const uint8_t* data, const uin
 	const uint32_t prev = j == 0 ? 0u : ((((uint32_t)data[sorted[j - 1]] << 8) | data[sorted[j - 1] + 1]) + 1u);
 	for (uint32_t k = prev; k <= key; k++) bucket_off[k] = j; /* empty buckets in between start here too */
 }
+
+/* the two bytes after each indexed bigram, in bucket order (the input is zero padded past its end) */
+__global__ void __launch_bounds__(256) ix_next2(const uint8_t* data, const uint32_t* sorted, uint32_t m, uint16_t* nx)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	const uint32_t p = sorted[j];
+	nx[j] = (uint16_t)((uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8));
+}

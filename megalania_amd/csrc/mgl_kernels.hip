@@ -31,7 +31,7 @@ __device__ __forceinline__ uint64_t topk_make_key(uint32_t cost, uint64_t seq)
 }
 __device__ __forceinline__ uint64_t topk_threshold(const TopK& t)
 {
-	return t.count < t.k ? MGL_INVALID_COST : shfl64(t.key, (int)t.k - 1);
+	return t.count < t.k ? MGL_INVALID_COST : rdlane64(t.key, t.k - 1u); /* count and k are uniform */
 }
 /* every lane may offer one candidate key (or ~0); all offers better than the current
  * K-th best are merged into the sorted list */
@@ -162,6 +162,20 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	if (lane < 16) aligncost[lane] = rev_tree_cost(probs, T, MGL_OFF_DIST + MGL_DIST_ALIGN, lane, 4);
 	bool high_ready = false;
 	wave_sync();
+	/* per distance slot: the least a distance in that slot can cost in any length context (pruning bound) */
+	uint32_t* lbslot = lencost + 944;
+	{
+		const uint32_t slot = lane;
+		uint32_t m = slotcost[slot];
+		for (uint32_t k = 1; k < 4; k++) { const uint32_t v = slotcost[64u * k + slot]; m = v < m ? v : m; }
+		uint32_t amin = lane < 16 ? aligncost[lane] : 0xFFFFFFFFu;
+		for (int o = 8; o > 0; o >>= 1) { const uint32_t a2 = (uint32_t)__shfl_xor((int)amin, o, 64); amin = a2 < amin ? a2 : amin; }
+		amin = uni(amin);
+		/* direct bits + at least the cheapest align nibble; the reverse-tree tails of nearer slots count as 0 */
+		if (slot >= 14) m += (((slot >> 1) - 5u) << 11) + amin;
+		lbslot[slot] = m;
+	}
+	wave_sync();
 	if (c.diag_stop == 31) return;
 	/* cheapest length price of either coder over the lengths priced so far: lower bounds for pruning */
 	uint32_t minlen_m, minlen_r;
@@ -209,36 +223,64 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	const uint32_t inc_type = mgl_pk_type(incumbent), inc_len = mgl_pk_len(incumbent), inc_dist = mgl_pk_dist(incumbent);
 	if (c.diag_stop == 33) { t.count += (hi - lo) & 1u; return; }
 
-	for (uint32_t hb = lo; hb < hi; hb += 64) {
-		const uint32_t idx = hb + lane;
-		bool have = idx < hi;
-		uint32_t q = 0, d = 0, L = 0, repmask = 0;
+	/* the two bytes that follow the target's bigram; the index keeps the same two bytes of every
+	 * hit next to its position (bucket_nx), so a hit that matches fewer than four bytes -- most of
+	 * them -- is sized without touching the input at all */
+	const uint32_t x2 = (uint32_t)c.data[pos + 2] | ((uint32_t)c.data[pos + 3] << 8);
+	/* nearest hits first: they are the cheapest to code and win ties (later in the reference's
+	 * enumeration order), so the K-th best is close to final after the first batch and almost
+	 * every farther hit is turned away by the lower-bound test alone */
+	const uint32_t nhits = hi - lo;
+	/* Software pipeline over batches of 64 hits: the bucket entries of batch i+2 and the first
+	 * eight input bytes (offsets 4..11) of the long matches of batch i+1 are in flight while batch i
+	 * is priced. */
+	uint64_t x4;
+	__builtin_memcpy(&x4, c.data + pos + 4, 8);
+	uint32_t q = 0, nx = 0, q1 = 0, nx1 = 0, q2 = 0, nx2 = 0;
+	uint64_t y = 0, y1 = 0;
+	if (lane < nhits) { q = c.bucket_pos[hi - 1u - lane]; nx = c.bucket_nx[hi - 1u - lane]; }
+	if (64u + lane < nhits) { q1 = c.bucket_pos[hi - 65u - lane]; nx1 = c.bucket_nx[hi - 65u - lane]; }
+	if (lane < nhits && nx == x2) __builtin_memcpy(&y, c.data + q + 4, 8);
+	for (uint32_t hb = 0; hb < nhits; hb += 64) {
+		bool have = hb + lane < nhits;
+		if (hb + 64u + lane < nhits && nx1 == x2) __builtin_memcpy(&y1, c.data + q1 + 4, 8);
+		if (hb + 128u + lane < nhits) { q2 = c.bucket_pos[hi - 1u - (hb + 128u + lane)]; nx2 = c.bucket_nx[hi - 1u - (hb + 128u + lane)]; }
+		const uint32_t cq = q, cnx = nx;
+		const uint64_t cy = y;
+		q = q1; nx = nx1; y = y1; q1 = q2; nx1 = nx2; /* the waits these moves imply come after the pricing below */
+		if (c.diag_stop == 37) { t.key ^= (uint64_t)(cq + cnx); continue; }
+		uint32_t d = 0, L = 0, repmask = 0, slot = 0;
 		uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, tail = 0;
 		if (have) {
-			q = c.bucket_pos[idx];
-			d = pos - q - 1;
-			/* match extension, substring_enumerator.c:99-103, eight bytes per step (the input is
-			 * zero-padded past its end; global memory takes unaligned 8-byte loads) */
-			L = 2;
-			while (L < maxlen) {
-				uint64_t x, y;
-				__builtin_memcpy(&x, c.data + pos + L, 8);
-				__builtin_memcpy(&y, c.data + q + L, 8);
-				const uint64_t df = x ^ y;
-				if (df) { L += ((uint32_t)__ffsll((long long)df) - 1u) >> 3; break; }
-				L += 8;
+			d = pos - cq - 1;
+			/* match extension, substring_enumerator.c:99-103: bytes 2 and 3 from the index, then eight
+			 * bytes per step from the input (zero-padded past its end; global memory takes unaligned
+			 * 8-byte loads) */
+			const uint32_t df2 = cnx ^ x2;
+			L = (df2 & 0xFFu) ? 2u : (df2 >> 8) ? 3u : 4u;
+			if (L == 4 && c.diag_stop != 38) {
+				const uint64_t df4 = x4 ^ cy;
+				if (df4) L += ((uint32_t)__ffsll((long long)df4) - 1u) >> 3;
+				else {
+					L = 12;
+					while (L < maxlen) {
+						uint64_t x, yy;
+						__builtin_memcpy(&x, c.data + pos + L, 8);
+						__builtin_memcpy(&yy, c.data + cq + L, 8);
+						const uint64_t df = x ^ yy;
+						if (df) { L += ((uint32_t)__ffsll((long long)df) - 1u) >> 3; break; }
+						L += 8;
+					}
+				}
 			}
 			if (L > maxlen) L = maxlen;
 			repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
 			          (w.st.dists[3] == d ? 8u : 0u);
-			/* distance price per length context from the tables */
-			uint32_t slot = d;
+			slot = d;
 			if (d >= 4) {
 				const uint32_t nlow = mgl_msb32(d) - 2;
 				slot = nlow * 2 + (d >> nlow);
-				tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
 			}
-			s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
 		}
 		if (!high_ready && __ballot(have && L >= 18)) {
 			for (uint32_t l = 18 + lane; l <= MGL_MAX_MATCH; l += 64) {
@@ -255,7 +297,27 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 			}
 			minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
 		}
-		if (c.diag_stop == 34) { t.key ^= (uint64_t)(s0 + s1 + s2 + s3 + tail + L); continue; }
+		/* one table read decides for most hits: even the cheapest conceivable price at the longest
+		 * length this hit offers does not reach the current K-th best */
+		const uint64_t thr0 = topk_threshold(t);
+		const uint64_t lim0 = thr0 == MGL_INVALID_COST ? ~0ull : (thr0 >> 44) + 1ull;
+		uint32_t lb = 0;
+		if (have) {
+			const uint32_t lb_m = hdr_match + minlen_m + lbslot[slot];
+			const uint32_t lb_r = hdr_lr_min + minlen_r;
+			lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
+			if ((uint64_t)lb >= lim0 * L && c.diag_stop != 38 && c.diag_stop != 34) have = false;
+		}
+		if (!__ballot(have)) continue;
+		if (have) {
+			/* distance price per length context from the tables */
+			if (d >= 4) {
+				const uint32_t nlow = mgl_msb32(d) - 2;
+				tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
+			}
+			s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
+		}
+		if (c.diag_stop == 34 || c.diag_stop == 38) { t.key ^= (uint64_t)(s0 + s1 + s2 + s3 + tail + L); continue; }
 		/* Candidates of a hit: for every length 2..L the MATCH and a LONG_REP per rep slot that holds
 		 * this distance (packet_enumerator.c:48-54).  The selection is order-independent, so each lane
 		 * walks its hit from the longest length down (the cheapest per byte first, which tightens the
@@ -263,10 +325,6 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 		 * current K-th best any more.  The exact perp/len division is only done for candidates that
 		 * pass the multiply test. */
 		uint32_t len = L, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
-		const uint32_t smin = s0 < s1 ? (s0 < s2 ? (s0 < s3 ? s0 : s3) : (s2 < s3 ? s2 : s3)) : (s1 < s2 ? (s1 < s3 ? s1 : s3) : (s2 < s3 ? s2 : s3));
-		const uint32_t lb_m = hdr_match + minlen_m + smin + tail;
-		const uint32_t lb_r = hdr_lr_min + minlen_r;
-		const uint32_t lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
 		while (__ballot(have)) {
 			const uint64_t thr = topk_threshold(t);
 			/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
@@ -291,7 +349,7 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 				if (nk <= 4) kind = nk; else { kind = 0; len--; if (len < 2) have = false; }
 				if ((uint64_t)perp >= lim * clen || c.diag_stop == 36) continue;
 				if (ctype == inc_type && clen == inc_len && cdist == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
-				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(q + 1) << 12) | ((uint64_t)clen << 3) | ckind);
+				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(cq + 1) << 12) | ((uint64_t)clen << 3) | ckind);
 				if (key < thr) { cand = key; break; }
 			}
 			if (c.diag_stop != 35) topk_offer(t, cand, lane);

@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 				journal_set(jn, pos, first, m_first, lane);
 				pick_is_mutation = false;
 				prof_mark(prof, 2, lane); /* top-K */
-				if (c.diag_stop == 3 || (c.diag_stop >= 31 && c.diag_stop <= 36)) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = (uint32_t)m_first; } return; }
+				if (c.diag_stop == 3 || (c.diag_stop >= 31 && c.diag_stop <= 39)) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = (uint32_t)m_first; } return; }
 			} else {
 				picked_pk = ok ? picked : pick_inc;
 				have_pick = true;

@@ -199,7 +199,8 @@ def main():
                       "est_bytes_best": 18 + st["best_cost"] / 16384, "accepted": st["accepted"],
                       "gpu_ms_apply_avg": st["gpu_ms_rebuild"] / launches,
                       "gpu_ms_total": st["gpu_ms_total"], "full_rebuilds": st["full_rebuilds"],
-                      "fallback_neighbours": st["fallback_neighbours"]},
+                      "fallback_neighbours": st["fallback_neighbours"],
+                      "second_pass_neighbours": st["second_pass_neighbours"]},
         }
         traffic, src = pmc_traffic()
         if traffic is not None and args.config == "c2":

@@ -246,6 +246,8 @@ static int launch_apply(mgl_sa* sa)
 	hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
 	                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
+	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
+	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
 	if (sa->snapshots) {
 		int rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1);
@@ -321,6 +323,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo2); dfree(sa->d_counts);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
+	dfree(sa->ab.span_pos); dfree(sa->ab.span_ev); dfree(sa->ab.jobs_b); dfree(sa->ab.jobs_c);
 	dfree(sa->d_topk_pk); dfree(sa->d_topk_cost); dfree(sa->d_small); dfree(sa->d_sub_offs); dfree(sa->d_sub_lens);
 	for (hipEvent_t e : sa->ev_pool) (void)hipEventDestroy(e);
 	if (sa->ev_begin) (void)hipEventDestroy(sa->ev_begin);
@@ -422,7 +425,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		b.nw0 = (uint32_t)(((size_t)n + 63) / 64);
 		b.nw1 = (b.nw0 + 63) / 64;
 		b.nw2 = (b.nw1 + 63) / 64;
-		b.nck = b.nw0;
+		b.nck = (uint32_t)(((size_t)n + (1u << MGL_CK2_SHIFT) - 1) >> MGL_CK2_SHIFT);
 		b.ck_elems = ckpt_elems;
 		b.pool_cap = (uint32_t)(24 * n + (size_t)L.total * 272 + 4096);
 		size_t bytes = 0;
@@ -472,10 +475,11 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		{
 			ApplyBuf& ab = sa->ab;
 			memset(&ab, 0, sizeof ab);
-			/* one workgroup per touched context where memory allows (scratch = one chain region each) */
-			sa->apply_blocks = 128;
-			while (sa->apply_blocks > 8 && (size_t)sa->apply_blocks * (n + 64) * 6 > ((size_t)4 << 30)) sa->apply_blocks /= 2;
-			ab.scratch_stride = (uint32_t)n + 64u;
+			/* one workgroup per touched context plans the rewrite; the copies run as job lists */
+			sa->apply_blocks = 256;
+			ab.scratch_cap = b.pool_cap + 256u;
+			ab.span_cap = 1u << 20;
+			ab.job_cap = 1u << 18;
 			HIPCHK(hipMalloc(&ab.hdr, sizeof(uint32_t) * 16));
 			HIPCHK(hipMemset(ab.hdr, 0, sizeof(uint32_t) * 16));
 			HIPCHK(hipMalloc(&ab.ins_key, sizeof(uint16_t) * MGL_APPLY_CAP));
@@ -483,8 +487,12 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&ab.ins_pos, sizeof(uint32_t) * MGL_APPLY_CAP));
 			HIPCHK(hipMalloc(&ab.rem_pos, sizeof(uint32_t) * MGL_APPLY_CAP));
 			HIPCHK(hipMalloc(&ab.tctx, sizeof(uint16_t) * 16384));
-			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
-			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_stride * sa->apply_blocks));
+			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_cap));
+			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_cap));
+			HIPCHK(hipMalloc(&ab.span_pos, sizeof(uint32_t) * (size_t)ab.span_cap));
+			HIPCHK(hipMalloc(&ab.span_ev, sizeof(uint16_t) * (size_t)ab.span_cap));
+			HIPCHK(hipMalloc(&ab.jobs_b, sizeof(uint4) * (size_t)ab.job_cap));
+			HIPCHK(hipMalloc(&ab.jobs_c, sizeof(uint4) * (size_t)ab.job_cap));
 		}
 		{
 			/* journal + context bitmap + max(model + price tables, change lists + context list) */
@@ -904,6 +912,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
 	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
+	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
 	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
 	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */

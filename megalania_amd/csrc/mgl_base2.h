@@ -24,7 +24,7 @@
 
 #define MGL_CK2_SHIFT 6u
 #define MGL_POS_INF 0xFFFFFFFFu
-#define MGL_CHG_CAP 256u   /* inserted / removed events per neighbour kept in LDS */
+#define MGL_CHG_CAP 512u   /* inserted / removed events per neighbour kept in LDS */
 #define MGL_BIG_CAP 8192u   /* the same, per flagged neighbour, in the global scratch of the second pass */
 #define MGL_BIG_SLOTS 512u
 #ifndef MGL_NBR_WAVES_PER_SIMD

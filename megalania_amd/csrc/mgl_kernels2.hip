@@ -483,18 +483,19 @@ __device__ __forceinline__ void plan_at(const DevCtx& c, const mgl_wstate& st, u
 }
 
 /* The base's adaptive model before the first base packet at or after y, into LDS: dense
- * checkpoint + replay of < 64 bytes of base packets. */
+ * checkpoint + replay of < 2^MGL_CK2_SHIFT bytes of base packets. */
 __device__ void model_load(const DevCtx& c, const Base2& b, uint16_t* probs, const uint16_t* T, uint32_t y, uint32_t lane)
 {
 	const uint32_t ck = y >> MGL_CK2_SHIFT;
 	const uint32_t* src = (const uint32_t*)(b.ck_probs + (size_t)ck * b.ck_elems);
 	uint32_t* dst = (uint32_t*)probs;
 	for (uint32_t i = lane; i < b.ck_elems / 2; i += 64) dst[i] = src[i];
-	/* first base packet start in [ck*64, y) */
-	const uint64_t bits = b.onwalk[ck] & ((y & 63u) ? ((1ull << (y & 63u)) - 1ull) : 0ull);
+	/* first base packet start in [ck << shift, y): one bitmap word holds the whole checkpoint block */
+	const uint32_t first = ck << MGL_CK2_SHIFT;
+	const uint64_t bits = b.onwalk[first >> 6] & ((y & 63u) ? ((1ull << (y & 63u)) - 1ull) : 0ull) & (~0ull << (first & 63u));
 	wave_sync();
 	if (bits) {
-		const uint32_t start = uni((ck << 6) + ctz64(bits));
+		const uint32_t start = uni(((first >> 6) << 6) + ctz64(bits));
 		Walk w;
 		walk_reset(w);
 		w.st = uni_state(base_state_at(b, start));

@@ -22,6 +22,7 @@
 #define MGL_SPAN_CAP 4096u    /* rewritten chain entries per context */
 #define MGL_PIECE_CAP 160u
 #define MGL_APPLY_THREADS 1024u
+#define MGL_APPLY_WIN 2048u
 
 struct ApplyBuf {
 	uint32_t* hdr;      /* [0] n_ins [1] n_rem [2] n_tctx [3] first journal position */
@@ -30,10 +31,24 @@ struct ApplyBuf {
 	uint16_t* rem_key;
 	uint32_t* rem_pos;
 	uint16_t* tctx;
-	uint32_t* scratch_pos; /* per workgroup: scratch_stride entries */
+	/* chain rewrites are planned per context (k_apply_chains) and carried out as flat lists of copy
+	 * jobs by the whole device (k_apply_jobs): pass B saves the old entries, pass C writes the new */
+	uint32_t* scratch_pos; /* space 1: old chain entries saved by pass B (scratch_cap entries) */
 	uint16_t* scratch_ev;
-	uint32_t scratch_stride;
+	uint32_t scratch_cap;
+	uint32_t* span_pos;    /* space 2: re-simulated entries (span_cap entries) */
+	uint16_t* span_ev;
+	uint32_t span_cap;
+	uint4* jobs_b;         /* { src offset, dst offset, count, src space | dst space << 8 } */
+	uint4* jobs_c;
+	uint32_t job_cap;
 };
+/* hdr: [0] n_ins [1] n_rem [2] n_tctx [3] first journal position [4] jobs B [5] jobs C [6] span entries used
+ * [7] scratch entries used */
+#define MGL_JOB_CHUNK 4096u
+#define MGL_SPACE_CHAIN 0u
+#define MGL_SPACE_SCRATCH 1u
+#define MGL_SPACE_SPAN 2u
 
 __device__ __forceinline__ void bit_write(uint64_t* arr, uint32_t pos, bool on)
 {
@@ -208,6 +223,7 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 	}
 	if (lane == 0) {
 		ab.hdr[0] = n_ins; ab.hdr[1] = n_rem; ab.hdr[2] = failed ? 0u : nt; ab.hdr[3] = t;
+		ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0;
 		ctl->packets = (uint64_t)((int64_t)ctl->packets + dpackets);
 		ctl->rebuild_cost = ctl->cur_cost; /* exact cost of the new base */
 		if (failed) ctl->apply_failed = 1;
@@ -217,11 +233,13 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 /* first packet start at or after checkpoint ck's boundary (new walk), or MGL_POS_INF */
 __device__ __forceinline__ uint32_t ckpt_boundary(const Base2& b, uint32_t ck)
 {
-	uint32_t w = ck;
+	const uint32_t first = ck << MGL_CK2_SHIFT;
+	uint32_t w = first >> 6;
+	uint64_t keep = ~0ull << (first & 63u); /* the boundary may lie inside a bitmap word */
 	while (w < b.nw0) {
-		const uint64_t v = b.onwalk[w];
+		const uint64_t v = b.onwalk[w] & keep;
 		if (v) return (w << 6) + ctz64(v);
-		w++;
+		w++; keep = ~0ull;
 	}
 	return MGL_POS_INF;
 }
@@ -245,15 +263,20 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 	__shared__ uint32_t s_seg_lo[MGL_PIECE_CAP], s_seg_hi[MGL_PIECE_CAP], s_seg_first[MGL_PIECE_CAP], s_seg_last[MGL_PIECE_CAP];
 	__shared__ uint16_t s_seg_endp[MGL_PIECE_CAP];
 	__shared__ uint32_t s_wcount[16];
+	/* the chain entries the re-simulation is about to walk, fetched by the whole workgroup */
+	__shared__ uint32_t s_win_pos[MGL_APPLY_WIN];
+	__shared__ uint16_t s_win_ev[MGL_APPLY_WIN];
+	__shared__ uint32_t s_lo, s_hi, s_k, s_ns, s_job_b, s_job_c, s_span_base, s_scr_base;
 	__shared__ uint32_t s_ni, s_nr, s_npiece, s_nseg, s_k0, s_newtail, s_oldlen, s_fail, s_newlen, s_newoff, s_newcap;
 	if (!ctl->accepted_flag || ctl->apply_failed) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
 	const uint32_t n_ins = ab.hdr[0], n_rem = ab.hdr[1], nt = ab.hdr[2];
-	uint32_t* my_spos = ab.scratch_pos + (size_t)blockIdx.x * ab.scratch_stride;
-	uint16_t* my_sev = ab.scratch_ev + (size_t)blockIdx.x * ab.scratch_stride;
 
+	const bool prof = c.diag_stop == 50u; /* diagnostic: hdr[8..13] = slowest workgroup's cycles per stage */
 	for (uint32_t ti = blockIdx.x; ti < nt; ti += gridDim.x) {
 		const uint32_t cx = ab.tctx[ti];
+		unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull, t1;
+#define APPLY_STAGE(i_) if (prof && tid == 0) { t1 = __builtin_readcyclecounter(); atomicMax(&ab.hdr[8 + (i_)], (uint32_t)(t1 - t0)); t0 = t1; }
 		__syncthreads();
 		if (tid == 0) { s_ni = 0; s_nr = 0; s_fail = 0; }
 		__syncthreads();
@@ -291,36 +314,67 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 			}
 		}
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		APPLY_STAGE(0)
 
 		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
 		uint32_t* cpos = b.ch_pos + off;
 		uint16_t* cev = b.ch_ev + off;
-		/* ---- 2. re-simulate (one thread): new entries, pieces, checkpoint segments */
+		/* ---- 2. re-simulate: new entries, pieces, checkpoint segments.  First the whole workgroup
+		 * finds the chain entry of the first change (1024-ary search) and stages the entries from
+		 * there on in LDS; then one thread walks them. */
+		const uint32_t x0 = ((s_ni ? s_ipos[0] : MGL_POS_INF) < (s_nr ? s_rpos[0] : MGL_POS_INF)) ? s_ipos[0] : s_rpos[0];
+		if (tid == 0) { s_lo = 0; s_hi = len; }
+		__syncthreads();
+		for (;;) { /* invariant: entries before s_lo are < x0, entry s_hi is >= x0 (the sentinel is) */
+			const uint32_t lo = s_lo, hi = s_hi;
+			if (hi <= lo) break;
+			const uint32_t step = (hi - lo + MGL_APPLY_THREADS - 1u) / MGL_APPLY_THREADS;
+			const uint32_t idx = lo + tid * step;
+			const bool lt = idx < hi && cpos[idx] < x0;
+			const bool next_lt = (idx + step) < hi && cpos[idx + step] < x0;
+			__syncthreads();
+			if (tid == 0 && !lt) s_hi = lo; /* not even the first probe is below x0 */
+			__syncthreads();
+			if (lt && !next_lt) { s_lo = idx + 1u; s_hi = (idx + step) < hi ? (idx + step) : hi; }
+			__syncthreads();
+		}
+		const uint32_t k0c = s_lo;
+		for (uint32_t i = tid; i < MGL_APPLY_WIN; i += MGL_APPLY_THREADS) {
+			const bool in = k0c + i <= len;
+			s_win_pos[i] = in ? cpos[k0c + i] : MGL_POS_INF;
+			s_win_ev[i] = in ? cev[k0c + i] : (uint16_t)0;
+		}
+		__syncthreads();
+		APPLY_STAGE(1)
 		if (tid == 0) {
 			const uint32_t ni = s_ni, nr = s_nr;
 			uint32_t ii = 0, ri = 0, ns = 0, np = 0, nseg = 0;
-			const uint32_t x0 = (ni ? s_ipos[0] : MGL_POS_INF) < (nr ? s_rpos[0] : MGL_POS_INF) ? s_ipos[0] : s_rpos[0];
-			const uint32_t k0 = chain_lower_bound(cpos, len, x0);
+			const uint32_t k0 = k0c;
+#define CPOS(k_) (((k_) - k0) < MGL_APPLY_WIN ? s_win_pos[(k_) - k0] : cpos[(k_)])
+#define CEV(k_) (((k_) - k0) < MGL_APPLY_WIN ? (uint32_t)s_win_ev[(k_) - k0] : (uint32_t)cev[(k_)])
 			uint32_t k = k0, dst = 0;
-			uint32_t p = cev[k] & 0x7FFu;
 			bool fail = false;
 			uint32_t seg_first = 0, seg_lo = x0;
 			bool in_seg = true; /* a segment = a stretch where the new trajectory differs / entries change */
+			/* everything the loop compares lives in registers and is reloaded only when its cursor
+			 * moves; the next old entry is fetched one iteration ahead (one thread, LDS latency bound) */
+			uint32_t bpos = CPOS(k), ev = CEV(k);
+			uint32_t nbpos = bpos != MGL_POS_INF ? CPOS(k + 1) : MGL_POS_INF, nev = bpos != MGL_POS_INF ? CEV(k + 1) : 0u;
+			uint32_t ipos = ni ? s_ipos[0] : MGL_POS_INF, ibit = ni ? s_ibit[0] : 0u;
+			uint32_t rposn = nr ? s_rpos[0] : MGL_POS_INF;
+			uint32_t p = ev & 0x7FFu;
 			for (;;) {
 				const bool pending = ii < ni || ri < nr;
-				const uint32_t bpos = cpos[k];
-				const uint32_t ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF;
 				if (ipos < bpos) {
 					if (ns >= MGL_SPAN_CAP) { fail = true; break; }
-					s_span_pos[ns] = ipos; s_span_ev[ns] = (uint16_t)((s_ibit[ii] << 15) | p); ns++;
-					p = mgl_prob_update(p, s_ibit[ii]);
+					s_span_pos[ns] = ipos; s_span_ev[ns] = (uint16_t)((ibit << 15) | p); ns++;
+					p = mgl_prob_update(p, ibit);
 					ii++;
+					ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF; ibit = ii < ni ? s_ibit[ii] : 0u;
 					continue;
 				}
 				if (bpos == MGL_POS_INF) break; /* reached the sentinel */
-				const uint32_t ev = cev[k];
 				const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
-				const uint32_t rposn = ri < nr ? s_rpos[ri] : MGL_POS_INF;
 				const uint32_t nxt = ipos < rposn ? ipos : rposn;
 				if (p == bp && (!pending || nxt > bpos)) {
 					/* re-coupled at old entry k (which itself stays): close the segment */
@@ -336,18 +390,23 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 					s_piece[np].dst = dst; s_piece[np].src = k - k0; s_piece[np].count = k2 - k; s_piece[np].from_span = 0; np++;
 					dst += k2 - k;
 					k = k2;
-					p = cev[k] & 0x7FFu;
+					bpos = CPOS(k); ev = CEV(k);
+					nbpos = bpos != MGL_POS_INF ? CPOS(k + 1) : MGL_POS_INF; nev = bpos != MGL_POS_INF ? CEV(k + 1) : 0u;
+					p = ev & 0x7FFu;
 					seg_first = ns; seg_lo = nxt; in_seg = true;
 					continue;
 				}
-				if (ri < nr && s_rpos[ri] == bpos) {
+				if (rposn == bpos) {
 					ri++;
+					rposn = ri < nr ? s_rpos[ri] : MGL_POS_INF;
 				} else {
 					if (ns >= MGL_SPAN_CAP) { fail = true; break; }
 					s_span_pos[ns] = bpos; s_span_ev[ns] = (uint16_t)((bb << 15) | p); ns++;
 					p = mgl_prob_update(p, bb);
 				}
 				k++;
+				bpos = nbpos; ev = nev;
+				if (bpos != MGL_POS_INF) { nbpos = CPOS(k + 1); nev = CEV(k + 1); }
 			}
 			if (!fail && in_seg) {
 				/* ran into the sentinel un-coupled: the last segment reaches the end of the file */
@@ -369,39 +428,79 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 				newoff = atomicAdd(b.pool_top, newcap);
 				if (newoff + newcap > b.pool_cap) fail = true; /* pool exhausted: k_build compacts */
 			}
-			if ((len + 1 - k0) > ab.scratch_stride) fail = true;
 			s_newoff = newoff; s_newcap = newcap;
 			if (!fail) {
 				s_piece[np].dst = dst; s_piece[np].src = k - k0; s_piece[np].count = tail; s_piece[np].from_span = 0; np++;
 				/* an un-coupled end changes the context's final probability: the sentinel */
 			}
 			s_npiece = np; s_nseg = nseg; s_k0 = k0; s_oldlen = len; s_newlen = newlen; s_fail = fail ? 1u : 0u;
-			s_newtail = (cpos[k] == MGL_POS_INF && in_seg) ? (p | 0x10000u) : 0u; /* new sentinel value if un-coupled */
+			s_k = k; s_ns = ns;
+			s_newtail = (CPOS(k) == MGL_POS_INF && in_seg) ? (p | 0x10000u) : 0u; /* new sentinel value if un-coupled */
+#undef CPOS
+#undef CEV
 		}
 		__syncthreads();
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
-		const uint32_t k0 = s_k0, oldlen = s_oldlen;
-		/* ---- 3. copy the old region [k0, len] aside, then write the pieces back (or, when the
-		 * chain moves, write prefix and pieces straight to the new slot) */
+		APPLY_STAGE(2)
+		const uint32_t k0 = s_k0, oldlen = s_oldlen, newlen = s_newlen, kk = s_k, ns = s_ns, np = s_npiece;
+		/* ---- 3. the rewrite as copy jobs.  Pass B saves the old entries [k0, len] (only [k0, k) when the
+		 * tail neither shifts nor moves) and, for a chain that moves, copies its prefix to the new slot;
+		 * pass C writes every piece to its place: new entries from the span space, old ones from the
+		 * saved copy.  The tail -- by far the largest piece -- is cut into chunks so that the whole
+		 * device moves it. */
 		const bool moved = s_newoff != off;
-		uint32_t* npos = b.ch_pos + s_newoff;
-		uint16_t* nev = b.ch_ev + s_newoff;
-		for (uint32_t i = tid; i < oldlen + 1 - k0; i += MGL_APPLY_THREADS) { my_spos[i] = cpos[k0 + i]; my_sev[i] = cev[k0 + i]; }
-		if (moved) for (uint32_t i = tid; i < k0; i += MGL_APPLY_THREADS) { npos[i] = cpos[i]; nev[i] = cev[i]; }
-		__syncthreads();
-		for (uint32_t pi = 0; pi < s_npiece; pi++) {
-			const Piece pc = s_piece[pi];
-			for (uint32_t i = tid; i < pc.count; i += MGL_APPLY_THREADS) {
-				if (pc.from_span) { npos[k0 + pc.dst + i] = s_span_pos[pc.src + i]; nev[k0 + pc.dst + i] = s_span_ev[pc.src + i]; }
-				else { npos[k0 + pc.dst + i] = my_spos[pc.src + i]; nev[k0 + pc.dst + i] = my_sev[pc.src + i]; }
-			}
-		}
-		__syncthreads();
+		const bool tail_stays = !moved && newlen == oldlen;
+		const bool new_sentinel = (s_newtail & 0x10000u) != 0; /* then the tail is the old sentinel alone */
+		const uint32_t save_count = tail_stays ? (kk - k0) : (oldlen + 1u - k0);
+		const uint32_t tail_count = (tail_stays || new_sentinel) ? 0u : (oldlen + 1u - kk);
+		const uint32_t chunk_s = save_count / 512u > MGL_JOB_CHUNK ? (save_count + 511u) / 512u : MGL_JOB_CHUNK;
+		const uint32_t chunk_t = tail_count / 512u > MGL_JOB_CHUNK ? (tail_count + 511u) / 512u : MGL_JOB_CHUNK;
+		const uint32_t chunk_p = k0 / 512u > MGL_JOB_CHUNK ? (k0 + 511u) / 512u : MGL_JOB_CHUNK;
+		const uint32_t n_save = (save_count + chunk_s - 1u) / chunk_s;
+		const uint32_t n_prefix = moved ? (k0 + chunk_p - 1u) / chunk_p : 0u;
+		const uint32_t n_tail = (tail_count + chunk_t - 1u) / chunk_t;
+		const uint32_t n_small = np - 1u; /* every piece but the tail (always the last one) */
 		if (tid == 0) {
-			b.ch_len[cx] = s_newlen;
-			if (moved) { b.ch_off[cx] = s_newoff; b.ch_cap[cx] = s_newcap; }
-			if (s_newtail & 0x10000u) nev[s_newlen] = (uint16_t)(s_newtail & 0x7FFu);
+			s_job_b = atomicAdd(&ab.hdr[4], n_save + n_prefix);
+			s_job_c = atomicAdd(&ab.hdr[5], n_small + n_tail + (new_sentinel ? 1u : 0u));
+			s_span_base = atomicAdd(&ab.hdr[6], ns + 1u);
+			s_scr_base = atomicAdd(&ab.hdr[7], save_count);
+			if (s_job_b + n_save + n_prefix > ab.job_cap || s_job_c + n_small + n_tail + 1u > ab.job_cap ||
+			    s_span_base + ns + 1u > ab.span_cap || s_scr_base + save_count > ab.scratch_cap)
+				s_fail = 1;
 		}
+		__syncthreads();
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		const uint32_t jb = s_job_b, jc = s_job_c, spb = s_span_base, scb = s_scr_base, noff = s_newoff;
+		for (uint32_t i = tid; i < ns; i += MGL_APPLY_THREADS) { ab.span_pos[spb + i] = s_span_pos[i]; ab.span_ev[spb + i] = s_span_ev[i]; }
+		if (tid == 0 && new_sentinel) { ab.span_pos[spb + ns] = MGL_POS_INF; ab.span_ev[spb + ns] = (uint16_t)(s_newtail & 0x7FFu); }
+		for (uint32_t i = tid; i < n_save; i += MGL_APPLY_THREADS) {
+			const uint32_t at = i * chunk_s, cnt = (save_count - at) < chunk_s ? (save_count - at) : chunk_s;
+			ab.jobs_b[jb + i] = make_uint4(off + k0 + at, scb + at, cnt, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
+		}
+		for (uint32_t i = tid; i < n_prefix; i += MGL_APPLY_THREADS) {
+			const uint32_t at = i * chunk_p, cnt = (k0 - at) < chunk_p ? (k0 - at) : chunk_p;
+			ab.jobs_b[jb + n_save + i] = make_uint4(off + at, noff + at, cnt, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8));
+		}
+		for (uint32_t i = tid; i < n_small; i += MGL_APPLY_THREADS) {
+			const Piece pc = s_piece[i];
+			ab.jobs_c[jc + i] = pc.from_span ? make_uint4(spb + pc.src, noff + k0 + pc.dst, pc.count, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8))
+			                                 : make_uint4(scb + pc.src, noff + k0 + pc.dst, pc.count, MGL_SPACE_SCRATCH | (MGL_SPACE_CHAIN << 8));
+		}
+		{
+			const Piece tp = s_piece[np - 1u]; /* { dst, src = k - k0, count = len + 1 - k, from old } */
+			for (uint32_t i = tid; i < n_tail; i += MGL_APPLY_THREADS) {
+				const uint32_t at = i * chunk_t, cnt = (tail_count - at) < chunk_t ? (tail_count - at) : chunk_t;
+				ab.jobs_c[jc + n_small + i] = make_uint4(scb + tp.src + at, noff + k0 + tp.dst + at, cnt, MGL_SPACE_SCRATCH | (MGL_SPACE_CHAIN << 8));
+			}
+			if (tid == 0 && new_sentinel)
+				ab.jobs_c[jc + n_small + n_tail] = make_uint4(spb + ns, noff + k0 + tp.dst, 1u, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8));
+		}
+		if (tid == 0) {
+			b.ch_len[cx] = newlen;
+			if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
+		}
+		APPLY_STAGE(3)
 		/* ---- 4. dense checkpoints: this context's value wherever its trajectory changed */
 		for (uint32_t sg = 0; sg < s_nseg; sg++) {
 			const uint32_t lo = s_seg_lo[sg], hi = s_seg_hi[sg];
@@ -419,6 +518,9 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 				b.ck_probs[(size_t)ck * b.ck_elems + cx] = v;
 			}
 		}
+		__syncthreads();
+		APPLY_STAGE(4)
+#undef APPLY_STAGE
 	}
 }
 
@@ -490,5 +592,25 @@ __global__ void __launch_bounds__(256) k_snapshot(SnapPlan p, Control* ctl, Snap
 		for (unsigned long long i = tid; i < vecs; i += nthreads) dst[i] = src[i];
 		const unsigned long long done = vecs << 4;
 		if (tid < bytes - done) ((uint8_t*)g.dst)[done + tid] = ((const uint8_t*)g.src)[done + tid];
+	}
+}
+
+
+/* carry out one list of copy jobs: entries (position u32 + event u16) between the chain pool, the
+ * save area and the span area */
+__global__ void __launch_bounds__(256) k_apply_jobs(Base2 b, const Control* ctl, ApplyBuf ab, int pass)
+{
+	if (!ctl->accepted_flag || ctl->apply_failed) return;
+	const uint32_t njobs = ab.hdr[pass == 0 ? 4 : 5];
+	const uint4* jobs = pass == 0 ? ab.jobs_b : ab.jobs_c;
+	for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+		const uint4 job = jobs[j];
+		const uint32_t ss = job.w & 0xFFu, ds = (job.w >> 8) & 0xFFu;
+		const uint32_t* sp = ss == MGL_SPACE_CHAIN ? b.ch_pos : ss == MGL_SPACE_SCRATCH ? ab.scratch_pos : ab.span_pos;
+		const uint16_t* se = ss == MGL_SPACE_CHAIN ? b.ch_ev : ss == MGL_SPACE_SCRATCH ? ab.scratch_ev : ab.span_ev;
+		uint32_t* dp = ds == MGL_SPACE_CHAIN ? b.ch_pos : ab.scratch_pos;
+		uint16_t* de = ds == MGL_SPACE_CHAIN ? b.ch_ev : ab.scratch_ev;
+		sp += job.x; se += job.x; dp += job.y; de += job.y;
+		for (uint32_t i = threadIdx.x; i < job.z; i += blockDim.x) { dp[i] = sp[i]; de[i] = se[i]; }
 	}
 }

@@ -71,12 +71,15 @@ def check_base(sa, o, slab, data):
     pk_state = dict(zip((int(p) for p in tr["pk_pos"]), tr["pk_state"]))
     for p in np.nonzero(special)[0]:
         assert (st[p, :5] == pk_state[int(p)]).all(), p
-    # dense checkpoints: model before the first packet at or after every 64th byte
+    # dense checkpoints: model before the first packet at or after every `spacing`-th byte
     ck = sa.debug_dump(7, np.uint16).reshape(-1, (total + 7) // 8 * 8)
+    spacing = [s for s in (8, 16, 32, 64) if (n + s - 1) // s == ck.shape[0]]
+    assert len(spacing) >= 1, (n, ck.shape)
+    spacing = spacing[0]
     probs = np.full(total, 1024, dtype=np.int64)
     ei, nck = 0, 0
     for p in w:
-        while nck * 64 <= p:
+        while nck * spacing <= p:
             assert (ck[nck, :total] == probs).all(), nck
             nck += 1
         while ei < len(ctx) and tr["pos"][ei] == p:

@@ -11,5 +11,10 @@ sa = binding.SA(data, neighbours_per_step=4096, timing=True)
 fb = []
 for s in range(steps):
     st = sa.run(1)
-    fb.append((int(sa.debug_dump(10, np.uint32)[0]), round(st["gpu_ms_neighbours"], 2), st["packets"], st["failed"]))
-print(fb)
+    cnt = sa.debug_dump(10, np.uint32)
+    fb.append((int(cnt[0]), int(cnt[1]), int(cnt[2]), round(st["gpu_ms_neighbours"], 2), st["packets"], st["failed"]))
+a = np.array(fb, dtype=np.float64)
+print("columns: first-pass overflows, second-pass overflows, spill slots used, kernel ms, packets, failed")
+for lo in range(0, steps, 20):
+    blk = a[lo:lo + 20]
+    print(lo, "mean", np.round(blk.mean(axis=0), 2), "max", blk.max(axis=0))

@@ -37,12 +37,42 @@ __device__ __forceinline__ uint64_t topk_threshold(const TopK& t)
  * K-th best are merged into the sorted list */
 __device__ __forceinline__ void topk_offer(TopK& t, uint64_t cand, uint32_t lane)
 {
+	const uint64_t thr0 = topk_threshold(t);
+	unsigned long long m = __ballot(cand < thr0);
+	if (!m) return;
+	if (__popcll(m) >= 4) {
+		/* many at once: rank every element of (list + qualifying offers) among all of them -- keys
+		 * are distinct -- and send each to the lane of its rank */
+		uint32_t less_e = 0, less_c = 0, e_less = 0;
+		for (unsigned long long mm = m; mm; mm &= mm - 1ull) {
+			const uint32_t j = (uint32_t)__ffsll((long long)mm) - 1u;
+			const uint64_t x = rdlane64(cand, j);
+			less_e += x < t.key ? 1u : 0u;
+			less_c += x < cand ? 1u : 0u;
+			const uint32_t below = (uint32_t)__popcll(__ballot(t.key < x)); /* list keys below offer j */
+			if (lane == j) e_less = below;
+		}
+		const bool mine = (m >> lane) & 1ull;
+		uint32_t dest_e = lane < t.count ? lane + less_e : 63u;
+		uint32_t dest_c = mine ? e_less + less_c : 63u;
+		dest_e = dest_e < 63u ? dest_e : 63u; dest_c = dest_c < 63u ? dest_c : 63u;
+		const uint64_t ve = lane < t.count ? t.key : 0ull, vc = mine ? cand : 0ull;
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest_e << 2), (int)(uint32_t)ve) |
+		                    (uint32_t)__builtin_amdgcn_ds_permute((int)(dest_c << 2), (int)(uint32_t)vc);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest_e << 2), (int)(uint32_t)(ve >> 32)) |
+		                    (uint32_t)__builtin_amdgcn_ds_permute((int)(dest_c << 2), (int)(uint32_t)(vc >> 32));
+		uint32_t nc = t.count + (uint32_t)__popcll(m);
+		nc = nc < t.k ? nc : t.k;
+		t.count = nc;
+		t.key = lane < nc ? ((uint64_t)lo | ((uint64_t)hi << 32)) : MGL_INVALID_COST;
+		return;
+	}
 	for (;;) {
 		uint64_t thr = topk_threshold(t);
-		unsigned long long m = __ballot(cand < thr);
+		m = __ballot(cand < thr);
 		if (!m) break;
 		int src = __ffsll((long long)m) - 1;
-		uint64_t x = shfl64(cand, src);
+		uint64_t x = rdlane64(cand, (uint32_t)src);
 		uint32_t r = (uint32_t)__popcll(__ballot(t.key < x));
 		uint64_t up = shfl_up64(t.key, 1);
 		if (lane == r) t.key = x;

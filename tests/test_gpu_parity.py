@@ -257,3 +257,33 @@ def test_match_index_built_on_device(cfg, size):
     assert (got_off == want_off).all()
     assert (got_pos == want_pos).all()
     sa.close()
+
+
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (0, 2, 0), (1, 1, 1), (4, 0, 0)])
+def test_literal_context_and_position_bits(lc, lp, pb):
+    """lc / lp / pb beyond the reference's hard-coded 0/0/0 (main.c:45; xz's default is
+    3/0/2).  No reference implementation exists for these (parity unpinned): the device must equal
+    the CPU restatement, which follows the standard LZMA context definitions, and the emitted
+    stream must decode with liblzma."""
+    data, _ = corpus.config_input("c2", 12000)
+    K, seed = 192, 5
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed, lc=lc, lp=lp, pb=pb)
+    o = Oracle(data, lc=lc, lp=lp, pb=pb, dict_limit=0x400000)
+    base = literal_slab(len(data))
+    assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]
+    costs, nd, diffs = sa.neighbours(1)
+    for j in range(0, K, 6):
+        ok, cost, od = o.neighbour(base, seed, 1, j, keep=False)
+        assert int(costs[j]) == (cost if ok else binding.INVALID_COST), j
+    sa.run(25)
+    cur, cost = sa.current()
+    assert cost == o.cost_slab(cur.astype(base.dtype))["total"]
+    costs, nd, diffs = sa.neighbours(77)
+    curo = cur.astype(base.dtype)
+    for j in range(0, K, 12):
+        ok, c2, od = o.neighbour(curo, seed, 77, j, keep=False)
+        assert int(costs[j]) == (c2 if ok else binding.INVALID_COST), j
+    stream = binding.emit_stream(data, cur, lc=lc, lp=lp, pb=pb)
+    assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
+    assert abs((18 + cost / 16384) - len(stream)) <= 8 + len(stream) / 1000
+    sa.close()

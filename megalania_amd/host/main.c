@@ -12,6 +12,7 @@
  * use --epochs / --steps to bound the run.
  */
 #include <fcntl.h>
+#include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,7 +26,11 @@ static void usage(const char* argv0)
 {
 	fprintf(stderr,
 	        "usage: %s [--neighbours K] [--epochs E] [--phases P] [--steps S] [--seed N]\n"
-	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M] filename\n", argv0);
+	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M]\n"
+	        "          [-o out.lzma] [--save-slab file] [--load-slab file] filename\n"
+	        "  -o           write the stream to a file instead of stdout\n"
+	        "  --save-slab  after every epoch, write the best packet slab (resumable checkpoint)\n"
+	        "  --load-slab  start from a slab written by --save-slab (same input, same lc/lp/pb)\n", argv0);
 }
 
 int main(int argc, char** argv)
@@ -39,6 +44,7 @@ int main(int argc, char** argv)
 	unsigned epochs = 200, phases = 3;  /* main.c:66,69 */
 	unsigned long long steps_override = 0;
 	const char* filename = NULL;
+	const char *out_path = NULL, *save_path = NULL, *load_path = NULL;
 	for (int i = 1; i < argc; i++) {
 		const char* a = argv[i];
 		const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -54,6 +60,9 @@ int main(int argc, char** argv)
 		else if (!strcmp(a, "--pb")) props.pb = (uint8_t)strtoul(v, NULL, 0);
 		else if (!strcmp(a, "--device")) cfg.device = (int32_t)strtol(v, NULL, 0);
 		else if (!strcmp(a, "--max-scan")) cfg.max_bucket_scan = (uint32_t)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "-o")) out_path = v;
+		else if (!strcmp(a, "--save-slab")) save_path = v;
+		else if (!strcmp(a, "--load-slab")) load_path = v;
 		else { usage(argv[0]); return -1; }
 		i++;
 	}
@@ -76,32 +85,62 @@ int main(int argc, char** argv)
 	mgl_sa* sa = mgl_sa_create(file_data, file_size, props, &cfg);
 	if (sa == NULL) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 
+	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
+	if (packets_best == NULL) { fprintf(stderr, "Error: out of memory\n"); return -1; }
+	bool resumed = false;
+	if (load_path) {
+		/* slab file: "MGLSLAB1", u64 size, u64 perplexity, size x 12-byte packets (lzma_packet.h:13-17) */
+		FILE* f = fopen(load_path, "rb");
+		char magic[8];
+		uint64_t hdr[2] = { 0, 0 };
+		if (!f || fread(magic, 8, 1, f) != 1 || memcmp(magic, "MGLSLAB1", 8) != 0 || fread(hdr, 8, 2, f) != 2 ||
+		    hdr[0] != file_size || fread(packets_best, sizeof(mgl_packet), file_size, f) != file_size) {
+			fprintf(stderr, "Error: %s is not a slab for this input\n", load_path);
+			return -1;
+		}
+		fclose(f);
+		/* the library re-costs the slab and refuses it unless the perplexity matches */
+		if (mgl_sa_set_best(sa, packets_best, hdr[1]) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+		resumed = true;
+	}
+
 	unsigned long long steps_per_epoch = (file_size + cfg.neighbours_per_step - 1) / cfg.neighbours_per_step;
 	if (steps_override) steps_per_epoch = steps_override;
 	for (unsigned phase = 0; phase < phases; phase++) {
 		for (unsigned epoch = 0; epoch < epochs; epoch++) {
-			if (mgl_sa_begin_epoch(sa, phase, phase != 0) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+			if (mgl_sa_begin_epoch(sa, phase, phase != 0 || resumed) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 			mgl_sa_stats st;
 			if (mgl_sa_run(sa, steps_per_epoch, &st) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 			/* main.c:97-99: 18 = 13 header bytes + 5 flush bytes, 16384 = 2048 * 8 */
 			fprintf(stderr, "current file size: %f\tbest: %f\tstep: %u\tepoch: %04u\t%.0f evals/s\n",
 			        18 + st.current_cost / 16384.f, 18 + st.best_cost / 16384.f, phase + 1, epoch,
 			        st.gpu_ms_total > 0 ? st.evaluations / (st.gpu_ms_total * 1e-3) : 0.0);
+			if (save_path && st.best_cost != 0) {
+				uint64_t hdr[2] = { file_size, 0 };
+				if (mgl_sa_best(sa, packets_best, &hdr[1]) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+				char tmp[4096];
+				snprintf(tmp, sizeof tmp, "%s.tmp", save_path);
+				FILE* f = fopen(tmp, "wb");
+				if (!f || fwrite("MGLSLAB1", 8, 1, f) != 1 || fwrite(hdr, 8, 2, f) != 2 ||
+				    fwrite(packets_best, sizeof(mgl_packet), file_size, f) != file_size || fclose(f) != 0 || rename(tmp, save_path) != 0)
+					fprintf(stderr, "warning: could not write %s\n", save_path);
+			}
 		}
 	}
 
-	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
 	uint64_t best = 0;
-	if (packets_best == NULL || mgl_sa_best(sa, packets_best, &best) != MGL_OK) {
+	if (mgl_sa_best(sa, packets_best, &best) != MGL_OK) {
 		fprintf(stderr, "Error: could not fetch the best slab: %s\n", mgl_last_error());
 		return -1;
 	}
 	mgl_sa_destroy(sa);
 
+	FILE* out = stdout;
+	if (out_path && (out = fopen(out_path, "wb")) == NULL) { fprintf(stderr, "Error: could not open %s\n", out_path); return -1; }
 	OutputInterface output;
-	mgl_file_output_new(&output, stdout);
+	mgl_file_output_new(&output, out);
 	if (!mgl_emit_stream(file_data, file_size, props, packets_best, &output)) return -1;
-	fflush(stdout);
+	if (out_path ? fclose(out) != 0 : fflush(stdout) != 0) { fprintf(stderr, "Error: could not write the stream\n"); return -1; }
 	free(packets_best);
 	munmap((void*)file_data, file_size);
 	close(fd);

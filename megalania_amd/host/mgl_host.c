@@ -78,13 +78,27 @@ typedef struct {
 	uint32_t range;
 	uint8_t cache;
 	uint64_t pending; /* cache byte + the 0xFF run behind it */
+	/* range_encoder.c:18-38 hands every byte to OutputInterface.write on its own; here they are
+	 * collected and handed over 64 KiB at a time through the same vtable (same bytes, same order) */
+	size_t fill;
+	bool write_failed;
+	uint8_t buf[65536];
 } mgl_rc;
 
 #define MGL_RC_TOP 0x01000000u
 
+static void rc_flush(mgl_rc* rc)
+{
+	if (rc->fill && !(*rc->output->write)(rc->output, rc->buf, rc->fill) && !rc->write_failed) {
+		fprintf(stderr, "could not write %zu bytes\n", rc->fill); /* logged only, like range_encoder.c:29-31 */
+		rc->write_failed = true;
+	}
+	rc->fill = 0;
+}
 static void rc_emit(mgl_rc* rc, uint8_t byte)
 {
-	if (!(*rc->output->write)(rc->output, &byte, 1)) fprintf(stderr, "could not write: %02x\n", byte);
+	rc->buf[rc->fill++] = byte;
+	if (rc->fill == sizeof rc->buf) rc_flush(rc);
 }
 
 /* move the top byte of `low` out, resolving a possible carry into the bytes held back */
@@ -145,6 +159,8 @@ bool mgl_range_encoder_new(EncoderInterface* enc, OutputInterface* output)
 	rc->range = 0xFFFFFFFFu;
 	rc->cache = 0;
 	rc->pending = 1;
+	rc->fill = 0;
+	rc->write_failed = false;
 	enc->encode_bit = rc_encode_bit;
 	enc->encode_direct_bits = rc_encode_direct_bits;
 	enc->private_data = rc;
@@ -155,6 +171,7 @@ void mgl_range_encoder_free(EncoderInterface* enc)
 {
 	mgl_rc* rc = (mgl_rc*)enc->private_data;
 	for (int i = 0; i < 5; i++) rc_shift_low(rc);
+	rc_flush(rc);
 	free(rc);
 	enc->private_data = NULL;
 }

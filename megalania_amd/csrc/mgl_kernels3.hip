@@ -365,6 +365,33 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 			uint32_t p = ev & 0x7FFu;
 			for (;;) {
 				const bool pending = ii < ni || ri < nr;
+				if (!pending && in_seg) {
+					/* nothing left to insert or remove: follow the old entries until the probability
+					 * re-joins them, four staged entries per round of LDS reads */
+					bool moved_on = false;
+					for (;;) {
+						const uint32_t rel = k - k0;
+						if (rel + 4u > MGL_APPLY_WIN || ns + 4u > MGL_SPAN_CAP) break;
+						const uint32_t q0 = s_win_pos[rel], q1 = s_win_pos[rel + 1], q2 = s_win_pos[rel + 2], q3 = s_win_pos[rel + 3];
+						const uint32_t e0 = s_win_ev[rel], e1 = s_win_ev[rel + 1], e2 = s_win_ev[rel + 2], e3 = s_win_ev[rel + 3];
+						uint32_t took = 0;
+#define APPLY_FOLLOW(q_, e_) \
+						if (took == 4u || (q_) == MGL_POS_INF || p == ((e_) & 0x7FFu)) { if (took != 4u) took |= 8u; } \
+						else { s_span_pos[ns] = (q_); s_span_ev[ns] = (uint16_t)(((e_) & 0x8000u) | p); ns++; p = mgl_prob_update(p, (e_) >> 15); took++; }
+						APPLY_FOLLOW(q0, e0)
+						if (!(took & 8u)) { APPLY_FOLLOW(q1, e1) }
+						if (!(took & 8u)) { APPLY_FOLLOW(q2, e2) }
+						if (!(took & 8u)) { APPLY_FOLLOW(q3, e3) }
+#undef APPLY_FOLLOW
+						k += took & 7u;
+						moved_on = moved_on || (took & 7u) != 0;
+						if (took & 8u) break; /* sentinel or re-coupled at entry k: the general code below closes up */
+					}
+					if (moved_on) {
+						bpos = CPOS(k); ev = CEV(k);
+						nbpos = bpos != MGL_POS_INF ? CPOS(k + 1) : MGL_POS_INF; nev = bpos != MGL_POS_INF ? CEV(k + 1) : 0u;
+					}
+				}
 				if (ipos < bpos) {
 					if (ns >= MGL_SPAN_CAP) { fail = true; break; }
 					s_span_pos[ns] = ipos; s_span_ev[ns] = (uint16_t)((ibit << 15) | p); ns++;

@@ -242,18 +242,21 @@ static int rebuild_base(mgl_sa* sa, int after_accept)
 /* incremental engine, after k_decide: fold the winner into the base structures */
 static int launch_apply(mgl_sa* sa)
 {
+	/* the base is about to leave the best slab it still holds: keep a copy first (lazy: while every
+	 * accepted step is a new best no copy is ever taken) */
+	if (sa->snapshots) {
+		int rc = launch_snapshot(sa, sa->snap_best, 1, 0, 2);
+		if (rc) return rc;
+	}
 	hipLaunchKernelGGL(k_apply_walk, dim3(1), dim3(64), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, sa->ab);
-	hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
-	                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+	if (!sa->snapshots)
+		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
+		                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
-	if (sa->snapshots) {
-		int rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1);
-		if (rc) return rc;
-	}
-	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl);
+	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->snapshots ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -310,7 +313,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	if (sa->stream) (void)hipStreamSynchronize(sa->stream);
 	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_bucket_nx); dfree(sa->d_cost_tbl);
 	free_base(sa->base); free_base(sa->scratch);
-	dfree(sa->d_best);
+	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
@@ -386,7 +389,6 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 
 	HIPCHK(alloc_base(sa->base, (uint32_t)n, ckpt_elems));
 	HIPCHK(alloc_base(sa->scratch, (uint32_t)n, ckpt_elems));
-	HIPCHK(hipMalloc(&sa->d_best, sizeof(mgl_pk) * n));
 
 	const size_t K = sa->cfg.neighbours_per_step;
 	HIPCHK(hipMalloc(&sa->nbr.cost, sizeof(uint64_t) * K));
@@ -463,6 +465,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			}
 			HIPCHK(hipMalloc(&sa->d_snap_meta, sizeof(SnapMeta) * 2));
 			HIPCHK(hipMemset(sa->d_snap_meta, 0, sizeof(SnapMeta) * 2));
+			sa->d_best = sa->snap_best.slab; /* packets_best lives in the best snapshot */
 		}
 		if (sa->cfg.flags & MGL_F_PROFILE) {
 			HIPCHK(hipMalloc(&sa->d_prof, sizeof(unsigned long long) * (32 + K)));
@@ -541,6 +544,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 
 	/* packet_slab_new: all-literal current and best slabs */
 	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
+	if (!sa->d_best) HIPCHK(hipMalloc(&sa->d_best, sizeof(mgl_pk) * n));
 	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->d_best, sa->ctx.n);
 	HIPCHK(hipGetLastError());
 	int rc = rebuild_base(sa, 0);
@@ -589,6 +593,16 @@ static int write_ctl(mgl_sa* sa, BaseMem& b, const Control* in)
 	return MGL_OK;
 }
 
+/* the base still is the only holder of the best slab's structures and is about to be replaced */
+static int keep_best_before_overwrite(mgl_sa* sa, Control& c)
+{
+	if (!(sa->incremental && sa->snapshots) || !c.best_is_current) return MGL_OK;
+	int rc = launch_snapshot(sa, sa->snap_best, 1, 0, 0);
+	if (rc) return rc;
+	c.best_is_current = 0;
+	return MGL_OK;
+}
+
 extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 {
 	if (!sa) return fail(MGL_EINVAL, "null handle");
@@ -596,10 +610,13 @@ extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 	Control c;
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
+	if (from_best && c.best_cost == 0) from_best = 0; /* no best yet: packets_best is still the all-literal slab */
+	const bool snaps = sa->incremental && sa->snapshots;
+	const bool base_is_best = snaps && c.best_is_current;
+	if (!from_best && (rc = keep_best_before_overwrite(sa, c))) return rc;
 	c.iter = 0; c.cur_cost = 0; c.phase = phase; c.accepted_flag = 0; c.copy_best_flag = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
-	const bool snaps = sa->incremental && sa->snapshots;
-	if (from_best && c.best_cost == 0) from_best = 0; /* no best yet: packets_best is still the all-literal slab */
+	if (from_best && base_is_best) return MGL_OK; /* main.c:73-76 would copy packets_best over itself */
 	if (snaps) {
 		SnapMeta meta[2];
 		HIPCHK(hipMemcpyAsync(meta, sa->d_snap_meta, sizeof meta, hipMemcpyDeviceToHost, sa->stream));
@@ -627,10 +644,11 @@ extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
 {
 	if (!sa || !packets) return fail(MGL_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(sa->device));
-	int rc = import_slab(sa, packets, sa->base.v.slab);
-	if (rc) return rc;
 	Control c;
-	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
+	int rc = read_ctl(sa, sa->base, &c);
+	if (rc) return rc;
+	if ((rc = keep_best_before_overwrite(sa, c))) return rc;
+	if ((rc = import_slab(sa, packets, sa->base.v.slab))) return rc;
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
 	if ((rc = rebuild_base(sa, 0))) return rc;
@@ -736,7 +754,7 @@ extern "C" int mgl_sa_best(mgl_sa* sa, mgl_packet* packets_out, uint64_t* perple
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
 	if (perplexity_out) *perplexity_out = c.best_cost;
-	if (packets_out) return export_slab(sa, sa->d_best, packets_out);
+	if (packets_out) return export_slab(sa, (sa->incremental && sa->snapshots && c.best_is_current) ? sa->base.v.slab : sa->d_best, packets_out);
 	return MGL_OK;
 }
 
@@ -764,6 +782,7 @@ extern "C" int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t p
 	if (sa->d_snap_meta) HIPCHK(hipMemsetAsync(sa->d_snap_meta + 1, 0, sizeof(SnapMeta), sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
 	c.best_cost = perplexity;
+	c.best_is_current = 0;
 	return write_ctl(sa, sa->base, &c);
 }
 

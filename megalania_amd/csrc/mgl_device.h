@@ -62,6 +62,7 @@ struct Control {
 	uint32_t phase;
 	uint32_t accepted_flag, copy_best_flag, dirty_pos, winner;
 	uint32_t apply_failed; /* the incremental accept did not fit: rebuild from the slab */
+	uint32_t best_is_current; /* the base structures are the best slab's: no device copy of them exists yet */
 	uint32_t full_rebuilds;  /* accepts that went through k_build */
 	uint64_t fallback_nbrs;  /* neighbours costed by the full-walk kernel (did not fit the LDS lists) */
 	uint64_t big_nbrs;       /* neighbours redone by the second (global-scratch) pass */

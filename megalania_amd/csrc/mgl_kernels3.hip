@@ -552,9 +552,17 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 }
 
 /* decide-only variant of the step's tail: flags for k_build's conditional run are reset there */
-__global__ void k_step_end(Control* ctl)
+__global__ void k_step_end(Control* ctl, int lazy_best)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0) { ctl->accepted_flag = 0; ctl->apply_failed = 0; }
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		if (lazy_best) {
+			/* a new best: the base now is the best slab's; any other accepted move: they part ways
+			 * (k_snapshot kept a copy just before, see launch_apply) */
+			if (ctl->copy_best_flag) ctl->best_is_current = 1;
+			else if (ctl->accepted_flag) ctl->best_is_current = 0;
+		}
+		ctl->accepted_flag = 0; ctl->apply_failed = 0;
+	}
 }
 
 /* ================================================================== base snapshots
@@ -585,10 +593,12 @@ struct SnapMeta {
 };
 
 /* dir 0: base -> snapshot (meta taken from ctl); dir 1: snapshot -> base (ctl restored from meta).
- * cond != 0: only when this step produced a new best. */
+ * cond 1: only when this step produced a new best; cond 2: only when this step is about to move
+ * the base away from the best slab it still holds (the copy is taken lazily, at the last moment). */
 __global__ void __launch_bounds__(256) k_snapshot(SnapPlan p, Control* ctl, SnapMeta* meta, int dir, int cond)
 {
-	if (cond && !ctl->copy_best_flag) return;
+	if (cond == 1 && !ctl->copy_best_flag) return;
+	if (cond == 2 && !(ctl->accepted_flag && !ctl->copy_best_flag && ctl->best_is_current)) return;
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		if (dir == 0) {
 			meta->valid = 1u;

@@ -83,9 +83,12 @@ struct mgl_sa {
 	unsigned long long* d_prof; /* 16 u64: per-phase cycles + counts, only with MGL_F_PROFILE */
 	uint32_t* d_todo;       /* [0] = count, [1..K] = neighbour indices for the full-walk fallback */
 	uint32_t per_wave2, waves_per_block2, nbr2_lds, build_lds;
+	uint32_t per_wave_pick, per_wave_rest, pick_waves; /* LDS per wavefront of the two halves of the split launch */
 	size_t b2_bytes;
 	BigScratch big;
 	uint32_t* d_todo2;
+	uint4* d_pickrec;       /* K: picked packet, RNG position, ok flag (first half -> second half of the neighbour evaluation) */
+	bool split_nbr;
 	uint32_t* d_counts;     /* [0] first-pass overflow count, [1] second-pass overflow count, [2] spill slots used */
 	ApplyBuf ab;
 	uint32_t apply_blocks;
@@ -273,16 +276,27 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 	}
 	HIPCHK(hipMemsetAsync(sa->d_counts, 0, 4 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
-	hipLaunchKernelGGL(k_neighbours2<false>, dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
-	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
-	                   sa->d_prof, sa->big);
-	/* the few whose change lists overflowed LDS: same kernel, lists in global scratch */
-	const uint32_t bigblocks = (MGL_BIG_SLOTS + sa->waves_per_block2 - 1) / sa->waves_per_block2;
-	hipLaunchKernelGGL(k_neighbours2<true>, dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+	if (sa->split_nbr) {
+		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_PICK>), dim3((K + sa->pick_waves - 1) / sa->pick_waves), dim3(64 * sa->pick_waves),
+		                   4096u + sa->pick_waves * sa->per_wave_pick, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_pick, sa->d_todo, sa->d_counts,
+		                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec);
+		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(K), dim3(64), 4096u + sa->per_wave_rest, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
+		                   sa->d_prof, sa->big, sa->d_pickrec);
+	} else {
+		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
+		                   sa->d_prof, sa->big, sa->d_pickrec);
+	}
+	/* the few whose change lists overflowed LDS (or that need a second top-K pick): the whole
+	 * evaluation in one kernel, lists in global scratch */
+	const uint32_t bigblocks = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* one per neighbour: none is dropped */
+	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   (unsigned long long*)nullptr, sa->big);
+	                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec);
 	/* and whatever overflowed even that: exact full walk from byte 0 */
-	const uint32_t blocks = (MGL_BIG_SLOTS + sa->waves_per_block - 1) / sa->waves_per_block;
+	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
 	                   (const uint32_t*)sa->d_todo2, (const uint32_t*)(sa->d_counts + 1));
@@ -323,7 +337,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->d_todo2); dfree(sa->d_counts);
+	dfree(sa->d_todo2); dfree(sa->d_counts); dfree(sa->d_pickrec);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->ab.span_pos); dfree(sa->ab.span_ev); dfree(sa->ab.jobs_b); dfree(sa->ab.jobs_c);
@@ -503,11 +517,13 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			const uint32_t model = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u;
 			const uint32_t lists = MGL_CHG_CAP * (4u + 4u + 2u + 2u) + 2u * MGL_CHG_CAP * 2u;
 			sa->per_wave2 = (fixed + (model > lists ? model : lists) + 15u) & ~15u;
+			sa->per_wave_pick = (fixed + model + 15u) & ~15u;
+			sa->per_wave_rest = (fixed + lists + 15u) & ~15u;
 		}
 		{
 			BigScratch& g = sa->big;
 			memset(&g, 0, sizeof g);
-			g.cap = MGL_BIG_CAP; g.uctx_cap = ckpt_elems; g.slots = MGL_BIG_SLOTS;
+			g.cap = MGL_BIG_CAP; g.uctx_cap = ckpt_elems; g.slots = (uint32_t)(K > 512 ? K : 512); /* every neighbour of a step may need one */
 			HIPCHK(hipMalloc(&g.ins_key, sizeof(uint16_t) * (size_t)g.cap * g.slots));
 			HIPCHK(hipMalloc(&g.rem_key, sizeof(uint16_t) * (size_t)g.cap * g.slots));
 			HIPCHK(hipMalloc(&g.ins_pos, sizeof(uint32_t) * (size_t)g.cap * g.slots));
@@ -535,8 +551,14 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&sa->d_counts, sizeof(uint32_t) * 4));
 		HIPCHK(hipMemset(sa->d_counts, 0, sizeof(uint32_t) * 4));
 		sa->big.todo_in = sa->d_todo; sa->big.todo_in_count = sa->d_counts; sa->big.spill_ctr = sa->d_counts + 2;
-		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
-		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_PICK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_REST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
+		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;
+		sa->pick_waves = getenv("MGL_PICK_WAVES") ? (uint32_t)atoi(getenv("MGL_PICK_WAVES")) : 1u;
+		if (sa->pick_waves < 1 || 4096u + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = 1;
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
 
@@ -932,6 +954,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
 	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
 	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
+	case 15: src = sa->d_pickrec; sz = sa->d_pickrec ? sizeof(uint4) * sa->cfg.neighbours_per_step : 0; break;
 	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
 	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */

@@ -35,12 +35,12 @@ __device__ __forceinline__ uint64_t topk_threshold(const TopK& t)
 }
 /* every lane may offer one candidate key (or ~0); all offers better than the current
  * K-th best are merged into the sorted list */
-__device__ __forceinline__ void topk_offer(TopK& t, uint64_t cand, uint32_t lane)
+__device__ __forceinline__ void topk_offer(TopK& t, uint64_t cand, uint32_t lane, bool allow_batch = true)
 {
 	const uint64_t thr0 = topk_threshold(t);
 	unsigned long long m = __ballot(cand < thr0);
 	if (!m) return;
-	if (__popcll(m) >= 4) {
+	if (allow_batch && __popcll(m) >= 4) {
 		/* many at once: rank every element of (list + qualifying offers) among all of them -- keys
 		 * are distinct -- and send each to the lane of its rank */
 		uint32_t less_e = 0, less_c = 0, e_less = 0;
@@ -382,7 +382,7 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(cq + 1) << 12) | ((uint64_t)clen << 3) | ckind);
 				if (key < thr) { cand = key; break; }
 			}
-			if (c.diag_stop != 35) topk_offer(t, cand, lane);
+			if (c.diag_stop != 35) topk_offer(t, cand, lane, c.diag_stop != 80);
 		}
 	}
 }

@@ -525,11 +525,23 @@ struct BigScratch {
 	const uint32_t* todo_in; const uint32_t* todo_in_count;
 	uint32_t* spill_ctr; /* slots handed out to first-pass wavefronts that had to spill their lists */
 };
-template <bool BIG>
+/* MODE: the regular launch is split in two so that each half needs fewer registers and more
+ * wavefronts fit a SIMD (top-K is the register hog):
+ *   MGL_NBR_PICK  everything up to the mutated packet: target, walk state, and -- unless the
+ *                 mutation is a grow/shrink -- the model at the target and the top-K pick; the
+ *                 picked packet and the RNG position go to `pickrec`;
+ *   MGL_NBR_REST  recomputes the cheap part, takes the pick from `pickrec`, then window walk and
+ *                 chain re-simulation.  A repair that needs another top-K pick (rare) hands the
+ *                 neighbour to the next pass;
+ *   MGL_NBR_FULL  the whole thing in one kernel (the BIG second pass, which starts from scratch). */
+#define MGL_NBR_FULL 0
+#define MGL_NBR_PICK 1
+#define MGL_NBR_REST 2
+template <bool BIG, int MODE>
 __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
-                                                     BigScratch big)
+                                                     BigScratch big, uint4* pickrec)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
@@ -647,6 +659,8 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 	 * position) and the final one.  Halves the code size and the register pressure. */
 	enum { P_MODEL, P_SIM, P_TOPK, P_WALK, P_OUT };
 	uint32_t phase = mutated ? P_WALK : P_MODEL;
+	if (MODE == MGL_NBR_PICK && mutated) return; /* nothing to pick: the second half redoes the grow/shrink itself */
+	if (MODE == MGL_NBR_REST && c.diag_stop != 0 && c.diag_stop != 4 && c.diag_stop < 40) return; /* diagnostic stops of the first half */
 	/* pending top-K request */
 	bool pick_is_mutation = !mutated;
 	uint32_t pick_pos = pos;
@@ -664,9 +678,21 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 	uint32_t walked = 0;
 	bool first_packet = true;
 	uint32_t guard = 0;
+	if (MODE == MGL_NBR_REST && !mutated) {
+		const uint4 rec = pickrec[j];
+		if (!(rec.w & 1u)) { generate_failed = true; phase = P_OUT; }
+		else {
+			m_first = (mgl_pk)rec.x | ((mgl_pk)rec.y << 32);
+			journal_set(jn, pos, first, m_first, lane);
+			rng.n = rec.z;
+			pick_is_mutation = false;
+			phase = P_WALK;
+		}
+	}
 
 	for (;;) {
-		if (phase == P_MODEL) {
+		if (MODE == MGL_NBR_REST && (phase == P_MODEL || phase == P_TOPK)) { ch.overflow = true; phase = P_OUT; continue; } /* repair pick: next pass */
+		if (MODE != MGL_NBR_REST && phase == P_MODEL) {
 			/* the adaptive model the neighbour has at pick_pos: base model before the first base
 			 * packet at or after it (dense checkpoint + replay of < 64 bytes of base packets) ... */
 			if ((ch.n_ins + ch.n_rem) != 0 && !spilled) {
@@ -696,18 +722,22 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 			if ((ch.n_ins + ch.n_rem) != 0) { sim_limit = pick_pos; sim_overlay = true; phase = P_SIM; }
 			else phase = P_TOPK;
 		}
-		if (phase == P_SIM) {
-			const int64_t r = chain_sim(b, ch, T, sim_limit, sim_overlay ? probs : nullptr, lane, &too_many);
+		if (MODE != MGL_NBR_PICK && phase == P_SIM) {
+			const int64_t r = chain_sim(b, ch, T, sim_limit, (MODE != MGL_NBR_REST && sim_overlay) ? probs : nullptr, lane, &too_many);
 			wave_sync();
 			if (too_many) { phase = P_OUT; continue; }
 			if (sim_overlay) phase = P_TOPK;
 			else { delta = r; prof_mark(prof, 4, lane); phase = P_OUT; }
 		}
-		if (phase == P_TOPK) {
+		if (MODE != MGL_NBR_REST && phase == P_TOPK) {
 			walk_from_state(tw, nb);
 			walk_window(tw, c, b.slab, lane);
 			mgl_pk picked;
 			const bool ok = pick_from_top_k(c, tw, probs, T, lencost, pick_inc, pick_best, rng, lane, &picked);
+			if (MODE == MGL_NBR_PICK) {
+				if (lane == 0) pickrec[j] = make_uint4((uint32_t)picked, (uint32_t)(picked >> 32), rng.n, ok ? 1u : 0u);
+				return;
+			}
 			if (pick_is_mutation) {
 				if (!ok) { generate_failed = true; phase = P_OUT; continue; }
 				m_first = picked;
@@ -722,7 +752,7 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 			win.base = 0xFFFFFFFFu;
 			phase = P_WALK;
 		}
-		if (phase == P_WALK) {
+		if (MODE != MGL_NBR_PICK && phase == P_WALK) {
 			/* ---- two-pointer walk over neighbour packets (nb) and base packets (bs) */
 			bool request_pick = false;
 			while (nb.pos < c.n || bs.pos < c.n) {

@@ -557,8 +557,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
 		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;
-		sa->pick_waves = getenv("MGL_PICK_WAVES") ? (uint32_t)atoi(getenv("MGL_PICK_WAVES")) : 1u;
-		if (sa->pick_waves < 1 || 4096u + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = 1;
+		sa->pick_waves = 1; /* the kernel is built for one wavefront per workgroup (__launch_bounds__(64)) */
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
 

@@ -294,7 +294,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 	const uint32_t bigblocks = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* one per neighbour: none is dropped */
 	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec);
+	                   (unsigned long long*)nullptr, sa->big, sa->split_nbr ? sa->d_pickrec : (uint4*)nullptr);
 	/* and whatever overflowed even that: exact full walk from byte 0 */
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,

@@ -678,7 +678,8 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 	uint32_t walked = 0;
 	bool first_packet = true;
 	uint32_t guard = 0;
-	if (MODE == MGL_NBR_REST && !mutated) {
+	/* the second pass, too, takes the mutation's pick from the first half when there was one */
+	if ((MODE == MGL_NBR_REST || (BIG && pickrec != nullptr)) && !mutated) {
 		const uint4 rec = pickrec[j];
 		if (!(rec.w & 1u)) { generate_failed = true; phase = P_OUT; }
 		else {

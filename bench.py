@@ -13,8 +13,8 @@ the timed region.
 
 Rank 0 prints ONE JSON line.  `value` = neighbour evaluations that produced a cost, summed
 over all ranks, / max-over-ranks wall time of the K timed steps (inputs resident in HBM
-before the timed region).  `roofline` prices the dominant kernel (k_neighbours2, the
-incremental neighbour kernel, together with its two near-empty overflow passes) with SURVEY
+before the timed region).  `roofline` prices the dominant kernels (the two halves of the
+incremental neighbour evaluation, k_neighbours2<PICK> + <REST>, with their second pass) with SURVEY
 section 8d's algorithmic bytes B_eval = N + 12*P per evaluation against 8 TB/s, using the
 average duration from HIP events recorded on the library's own stream.  NOTE: the kernel is
 incremental -- it prices only the window a neighbour changes and re-joins the base model's
@@ -189,7 +189,7 @@ def main():
                        "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_neighbours2 (incremental; + overflow passes)", "avg_launch_ms": avg_ms,
+                         "kernel": "k_neighbours2<PICK> + k_neighbours2<REST> (the two halves of the incremental neighbour evaluation; + second pass)", "avg_launch_ms": avg_ms,
                          "launches_timed": launches,
                          "note": "achieved = evaluations/launch x (N + 12 P) / launch time: algorithmic bytes of the "
                                  "metric's unit (one exact whole-parse cost); the kernel prices only the changed window",

@@ -517,7 +517,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			const uint32_t model = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u;
 			const uint32_t lists = MGL_CHG_CAP * (4u + 4u + 2u + 2u) + 2u * MGL_CHG_CAP * 2u;
 			sa->per_wave2 = (fixed + (model > lists ? model : lists) + 15u) & ~15u;
-			sa->per_wave_pick = (fixed + model + 15u) & ~15u;
+			sa->per_wave_pick = (model + 15u) & ~15u; /* no journal / bitmap in the pick half */
 			sa->per_wave_rest = (fixed + lists + 15u) & ~15u;
 		}
 		{

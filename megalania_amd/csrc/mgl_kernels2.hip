@@ -572,7 +572,8 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 	Changes ch;
 	ch.nbitwords = (c.L.total + 31u) >> 5;
 	ch.ctxbits = jn.pos + MGL_MAX_DIFFS;
-	unsigned char* uni_base = (unsigned char*)(ch.ctxbits + ((ch.nbitwords + 3u) & ~3u));
+	/* the pick half never reads the journal or the bitmap: its wave area is the model + price tables alone */
+	unsigned char* uni_base = MODE == MGL_NBR_PICK ? mine : (unsigned char*)(ch.ctxbits + ((ch.nbitwords + 3u) & ~3u));
 	uint16_t* probs = (uint16_t*)uni_base;
 	uint32_t* lencost = (uint32_t*)(uni_base + (size_t)b.ck_elems * 2);
 	ch.ins_pos = (uint32_t*)uni_base;
@@ -641,14 +642,13 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 		if ((ft == MGL_LONG_REP || ft == MGL_MATCH) && flen > 2) {
 			m_second = mgl_pack(ft, mgl_pk_dist(first), flen - 1);
 			m_first = MGL_PK_LITERAL;
-			journal_set(jn, pos, first, m_first, lane);
-			journal_set(jn, pos + 1, second, m_second, lane);
+			if (MODE != MGL_NBR_PICK) { journal_set(jn, pos, first, m_first, lane); journal_set(jn, pos + 1, second, m_second, lane); }
 			second_set = true; mutated = true;
 		} else if ((ft == MGL_LITERAL || ft == MGL_SHORT_REP) && (st == MGL_MATCH || st == MGL_LONG_REP)) {
 			uint32_t rep_start = pos - (st == MGL_LONG_REP ? mgl_dist_at(&nb, sdist) : sdist);
 			if (slen < MGL_MAX_MATCH && rep_start > 0 && rep_start <= pos && win_byte(win, pos) == c.data[rep_start - 1]) {
 				m_first = mgl_pack(st, sdist, slen + 1);
-				journal_set(jn, pos, first, m_first, lane);
+				if (MODE != MGL_NBR_PICK) journal_set(jn, pos, first, m_first, lane);
 				mutated = true;
 			}
 		}

@@ -827,21 +827,33 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 					first_packet = false;
 					walked++;
 					const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
-					mgl_plan npl;
-					plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+					/* the base packet at the same position: identical coding cancels.  Which events a
+					 * packet produces depends on the packet, ctx_state, the position and -- for a literal
+					 * after a match -- the byte at rep distance 0; decided before anything is planned */
 					bool cancelled = false;
-					if (bs.pos == p) {
-						/* the base packet at the same position: identical coding cancels */
-						const mgl_pk bpk = win_pk(win, p);
-						const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
-						mgl_plan bpl;
-						plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
-						cancelled = bpk == pk && nb.ctx_state == bs.ctx_state &&
-						            (ntype != MGL_LITERAL || nb.ctx_state < 7 || npl.match_byte == bpl.match_byte);
-						if (!cancelled) changes_add<false>(ch, bpl, p, lane);
-						mgl_advance(&bs, btype, bdist, blen);
+					if (bs.pos == p && win_pk(win, p) == pk && nb.ctx_state == bs.ctx_state) {
+						cancelled = true;
+						if (ntype == MGL_LITERAL && nb.ctx_state >= 7) {
+							const uint32_t mn = nb.dists[0] < p ? c.data[p - nb.dists[0] - 1] : 0u;
+							const uint32_t mb = bs.dists[0] < p ? c.data[p - bs.dists[0] - 1] : 0u;
+							cancelled = mn == mb;
+						}
 					}
-					if (!cancelled) changes_add<true>(ch, npl, p, lane);
+					if (cancelled) {
+						mgl_advance(&bs, ntype, ndist, nlen);
+					} else {
+						if (bs.pos == p) {
+							const mgl_pk bpk = win_pk(win, p);
+							const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
+							mgl_plan bpl;
+							plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
+							changes_add<false>(ch, bpl, p, lane);
+							mgl_advance(&bs, btype, bdist, blen);
+						}
+						mgl_plan npl;
+						plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+						changes_add<true>(ch, npl, p, lane);
+					}
 					mgl_advance(&nb, ntype, ndist, nlen);
 				} else {
 					/* ---- a base packet the neighbour has already passed over: its events go away */

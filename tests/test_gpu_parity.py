@@ -287,3 +287,62 @@ def test_literal_context_and_position_bits(lc, lp, pb):
     assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
     assert abs((18 + cost / 16384) - len(stream)) <= 8 + len(stream) / 1000
     sa.close()
+
+
+def test_full_size_c3_properties():
+    """BASELINE configs[2] at full size (10 192 446 B, 16 384 neighbours/step): device cost == an
+    independent CPU walk of the device's slab after every step, sampled neighbour costs == oracle
+    (from the all-literal slab and from an evolved one), best slab == the parallel builder's and
+    the full-walk hook's cost, round trip through liblzma."""
+    data, _ = corpus.config_input("c3")
+    n = len(data)
+    K, seed = 16384, 1673551
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed)
+    o = Oracle(data, dict_limit=0x400000)
+    base = literal_slab(n)
+    assert sa.current()[1] == o.cost_slab(base)["total"]
+    costs, nd, diffs = sa.neighbours(0, want_diffs=False)
+    for j in (0, 5, 4097, 16383):
+        ok, cost, od = o.neighbour(base, seed, 0, j, keep=False)
+        assert int(costs[j]) == (cost if ok else binding.INVALID_COST), j
+    for s in range(6):
+        st = sa.run(1)
+        assert st["full_rebuilds"] == 0 and st["fallback_neighbours"] == 0
+    cur, cost = sa.current()
+    curo = cur.astype(base.dtype)
+    assert cost == st["current_cost"] == o.cost_slab(curo)["total"]
+    assert sa.cost_slab(P(curo))["total"] == cost          # the one-wavefront full walk agrees
+    costs, nd, diffs = sa.neighbours(77, want_diffs=False)
+    for j in (3, 9000):
+        ok, c2, od = o.neighbour(curo, seed, 77, j, keep=False)
+        assert int(costs[j]) == (c2 if ok else binding.INVALID_COST), j
+    sa.set_slab(cur)                                         # block-parallel rebuild of the evolved slab
+    assert sa.current()[1] == cost
+    bst, best_cost = sa.best()
+    stream = binding.emit_stream(data, bst)
+    assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
+    assert abs((18 + best_cost / 16384) - len(stream)) <= 8 + len(stream) / 1000
+    sa.close()
+
+
+def test_evolved_c2_neighbours_vs_oracle():
+    """Sampled neighbour costs against the oracle on an SA-evolved full-size c2 slab (many matches
+    and reps on the walk: the repair path and the second pass are exercised), both engines."""
+    data, _ = corpus.config_input("c2")
+    K, seed = 4096, 1673551
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed)
+    o = Oracle(data, dict_limit=0x400000)
+    sa.run(400)
+    cur, cost = sa.current()
+    curo = cur.astype(literal_slab(1).dtype)
+    assert cost == o.cost_slab(curo)["total"]
+    full = binding.SA(data, neighbours_per_step=K, seed=seed, fullwalk=True)
+    full.set_slab(cur)
+    ca, _, _ = sa.neighbours(400, want_diffs=False)
+    cf, _, _ = full.neighbours(400, want_diffs=False)
+    assert (ca == cf).all()
+    for j in range(0, K, 257):
+        ok, c2, od = o.neighbour(curo, seed, 400, j, keep=False)
+        assert int(ca[j]) == (c2 if ok else binding.INVALID_COST), j
+    sa.close()
+    full.close()

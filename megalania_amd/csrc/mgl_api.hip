@@ -88,7 +88,7 @@ struct mgl_sa {
 	BigScratch big;
 	uint32_t* d_todo2;
 	uint4* d_pickrec;       /* K: picked packet, RNG position, ok flag (first half -> second half of the neighbour evaluation) */
-	bool split_nbr;
+	bool split_nbr, adaptive; /* adaptive: the device switches between the split and the one-kernel form step by step */
 	uint32_t* d_counts;     /* [0] first-pass overflow count, [1] second-pass overflow count, [2] spill slots used */
 	ApplyBuf ab;
 	uint32_t apply_blocks;
@@ -259,7 +259,7 @@ static int launch_apply(mgl_sa* sa)
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
-	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->snapshots ? 1 : 0);
+	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->snapshots ? 1 : 0, (const uint32_t*)sa->d_counts, sa->adaptive ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -284,7 +284,8 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(K), dim3(64), 4096u + sa->per_wave_rest, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
 		                   sa->d_prof, sa->big, sa->d_pickrec);
-	} else {
+	}
+	if (!sa->split_nbr || sa->adaptive) { /* whichever form Control::nbr_single names does the work, the other returns at once */
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
 		                   sa->d_prof, sa->big, sa->d_pickrec);
@@ -557,6 +558,13 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
 		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;
+		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
+		if (!sa->split_nbr) { /* one-kernel form only */
+			Control c0;
+			HIPCHK(hipMemcpy(&c0, sa->base.ctl, sizeof c0, hipMemcpyDeviceToHost));
+			c0.nbr_single = 1;
+			HIPCHK(hipMemcpy(sa->base.ctl, &c0, sizeof c0, hipMemcpyHostToDevice));
+		}
 		sa->pick_waves = 1; /* the kernel is built for one wavefront per workgroup (__launch_bounds__(64)) */
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
@@ -953,6 +961,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
 	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
 	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
+	case 16: src = sa->base.ctl; sz = sizeof(Control); break; /* raw control block */
 	case 15: src = sa->d_pickrec; sz = sa->d_pickrec ? sizeof(uint4) * sa->cfg.neighbours_per_step : 0; break;
 	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
 	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;

@@ -63,6 +63,14 @@ struct Control {
 	uint32_t accepted_flag, copy_best_flag, dirty_pos, winner;
 	uint32_t apply_failed; /* the incremental accept did not fit: rebuild from the slab */
 	uint32_t best_is_current; /* the base structures are the best slab's: no device copy of them exists yet */
+	uint32_t nbr_single;    /* the next step evaluates neighbours with the one-kernel form (repairs are frequent) */
+	uint32_t mode_steps;    /* steps since the form last changed */
+	uint32_t probing;       /* steps left of a short trial of the other form (keeps its timing fresh) */
+	uint32_t ema_clean;     /* smoothed step duration, 10 ns ticks: split form, second pass empty ... */
+	uint32_t ema_dirty;     /* ... split form, second pass taken ... */
+	uint32_t ema_single;    /* ... one-kernel form */
+	uint32_t p_dirty;       /* smoothed probability (x 65536) that a step needs a repair pick / second pass */
+	unsigned long long t_last; /* wall clock at the end of the previous step */
 	uint32_t full_rebuilds;  /* accepts that went through k_build */
 	uint64_t fallback_nbrs;  /* neighbours costed by the full-walk kernel (did not fit the LDS lists) */
 	uint64_t big_nbrs;       /* neighbours redone by the second (global-scratch) pass */

@@ -543,9 +543,14 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
                                                      BigScratch big, uint4* pickrec)
 {
+	/* the step picks one of the two forms of the regular launch on the device (k_step_end): split
+	 * while repairs are rare (their second pass costs a lone wavefront's latency), one kernel
+	 * otherwise; the form not picked returns before touching anything */
+	const uint32_t form_single = BIG ? 0u : ctl->nbr_single; /* in flight together with the table loads below */
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	if (!BIG && ((MODE == MGL_NBR_FULL) != (form_single != 0))) return;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
@@ -679,7 +684,7 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 	bool first_packet = true;
 	uint32_t guard = 0;
 	/* the second pass, too, takes the mutation's pick from the first half when there was one */
-	if ((MODE == MGL_NBR_REST || (BIG && pickrec != nullptr)) && !mutated) {
+	if ((MODE == MGL_NBR_REST || (BIG && pickrec != nullptr && ctl->nbr_single == 0)) && !mutated) {
 		const uint4 rec = pickrec[j];
 		if (!(rec.w & 1u)) { generate_failed = true; phase = P_OUT; }
 		else {
@@ -816,6 +821,7 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 								if (ch.overflow) break;
 								resume_old = old; pick_pos = p; pick_inc = pk;
 								request_pick = true;
+								if (!BIG && lane == 0) atomicAdd(big.spill_ctr + 1, 1u); /* repair picks this step */
 								break; /* -> P_MODEL, then back here with have_pick */
 							}
 						}
@@ -905,5 +911,7 @@ __global__ void __launch_bounds__(64, MGL_NBR_WAVES_PER_SIMD) k_neighbours2(DevC
 		nd++;
 	}
 	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; }
-	if (prof_acc && lane == 0) prof_acc[32 + j] = __builtin_readcyclecounter() - t_begin; /* diagnostic: wave lifetime */
+	if (prof_acc && lane == 0) /* diagnostic: wave lifetime (40 bits) | change events (12 bits) | packets walked (12 bits) */
+		prof_acc[32 + j] = ((__builtin_readcyclecounter() - t_begin) & 0xFFFFFFFFFFull) |
+		                   ((unsigned long long)((ch.n_ins + ch.n_rem) & 0xFFFu) << 40) | ((unsigned long long)(walked & 0xFFFu) << 52);
 }

@@ -552,9 +552,46 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 }
 
 /* decide-only variant of the step's tail: flags for k_build's conditional run are reset there */
-__global__ void k_step_end(Control* ctl, int lazy_best)
+__global__ void k_step_end(Control* ctl, int lazy_best, const uint32_t* counts, int adaptive)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		if (adaptive) {
+			/* Which form of the regular neighbour launch runs the next step.  The split form has twice
+			 * the wavefronts per SIMD, but a neighbour that needs a repair pick costs it a second pass
+			 * at a lone wavefront's latency (~0.3 ms whatever the count).  Expected split step =
+			 * clean + p (dirty - clean), p = how often a step has such a neighbour (seen in either
+			 * form); the one-kernel form is used while its measured step is shorter than that. */
+			const unsigned long long now = (unsigned long long)wall_clock64();
+			const unsigned long long dt64 = now - ctl->t_last;
+			const uint32_t cur = ctl->nbr_single ? 1u : 0u;
+			const bool dirty = counts[0] != 0 || counts[3] != 0;
+			ctl->p_dirty = (uint32_t)((int32_t)ctl->p_dirty + (((dirty ? 65536 : 0) - (int32_t)ctl->p_dirty) >> 5));
+			if (ctl->t_last != 0 && ctl->mode_steps >= 1u && dt64 < 0x7FFFFFFFull) {
+				uint32_t* e = cur ? &ctl->ema_single : (dirty ? &ctl->ema_dirty : &ctl->ema_clean);
+				const uint32_t dt = (uint32_t)dt64;
+				if (*e == 0) *e = dt;
+				else if (dt < 4u * *e) *e = (15u * *e + dt) >> 4; /* longer: a host-side gap, not a step */
+			}
+			ctl->t_last = now;
+			ctl->mode_steps++;
+			uint32_t want = cur;
+			if (ctl->probing) {
+				if (--ctl->probing == 0) want = 1u - cur; /* trial over: back, then decide below on fresh numbers */
+			} else if (cur == 0u && counts[0] > 128u) {
+				want = 1u; /* a burst of repairs: hundreds of neighbours would go through the second pass */
+				ctl->p_dirty = ctl->p_dirty > 49152u ? ctl->p_dirty : 49152u;
+			} else if ((cur == 0u ? ctl->ema_single == 0 : (ctl->ema_clean == 0 && ctl->ema_dirty == 0)) ? ctl->mode_steps >= 8u : ctl->mode_steps >= 512u) {
+				want = 1u - cur; ctl->probing = 4; /* measure the other form for a few steps */
+			} else if ((ctl->ema_clean != 0 || ctl->ema_dirty != 0) && ctl->ema_single != 0) {
+				const uint32_t clean = ctl->ema_clean ? ctl->ema_clean : ctl->ema_dirty; /* no clean split step seen yet */
+				const uint32_t dirty_cost = ctl->ema_dirty > clean ? ctl->ema_dirty : clean + 30000u;
+				const unsigned long long exp_split = clean + (((unsigned long long)ctl->p_dirty * (dirty_cost - clean)) >> 16);
+				/* 4 % hysteresis around the incumbent */
+				if (cur == 0u) want = (unsigned long long)ctl->ema_single * 100ull < exp_split * 96ull ? 1u : 0u;
+				else want = exp_split * 100ull < (unsigned long long)ctl->ema_single * 96ull ? 0u : 1u;
+			}
+			if (want != cur) { ctl->nbr_single = want; ctl->mode_steps = 0; }
+		}
 		if (lazy_best) {
 			/* a new best: the base now is the best slab's; any other accepted move: they part ways
 			 * (k_snapshot kept a copy just before, see launch_apply) */

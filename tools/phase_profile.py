@@ -35,6 +35,14 @@ for i, nm in enumerate(names):
     print(f"  {nm:12s} {100*p[i]/tot:5.1f}%  calls={cnt}  avg cycles/call={p[i]/max(1,cnt):.0f}  max={int(p[16+i])}")
 print("  fallback (full-walk) neighbours in last step:", int(sa.debug_dump(10, np.uint32)[0]))
 print("  chain_sim max iterations:", int(p[21]), "ctx", int(p[22]), "chain len", int(p[23]) >> 32, "pending flags", int(p[23]) & 3, "n_ins", (int(p[23]) >> 8) & 0xFFF, "n_rem", (int(p[23]) >> 20) & 0xFFF)
-life = p[32:].astype(np.float64)
-life = life[life > 0]
+raw = p[32:]
+life = (raw & np.uint64(0xFFFFFFFFFF)).astype(np.float64)
+events = ((raw >> np.uint64(40)) & np.uint64(0xFFF)).astype(np.int64)
+walked = ((raw >> np.uint64(52)) & np.uint64(0xFFF)).astype(np.int64)
+ok = life > 0
+life, events, walked = life[ok], events[ok], walked[ok]
 print(f"  wave lifetime cycles (last launch): n={len(life)} mean={life.mean():.0f} p50={np.percentile(life,50):.0f} p90={np.percentile(life,90):.0f} p99={np.percentile(life,99):.0f} max={life.max():.0f}")
+print(f"  change events per neighbour: mean={events.mean():.0f} p90={np.percentile(events,90):.0f} max={events.max()};  packets walked: mean={walked.mean():.1f} max={walked.max()}")
+order = np.argsort(-life)[:12]
+print("  slowest waves (cycles, events, packets walked):", [(int(life[i]), int(events[i]), int(walked[i])) for i in order])
+print("  correlation lifetime~events:", round(float(np.corrcoef(life, events)[0, 1]), 3), " lifetime~walked:", round(float(np.corrcoef(life, walked)[0, 1]), 3))

@@ -76,7 +76,7 @@ typedef struct {
                              slow engine) instead of incrementally against the base chains;
                              both engines return identical numbers */
 
-#define MGL_F_PROFILE 4u  /* diagnostic: per-phase cycle counters in the neighbour kernel */
+#define MGL_F_PROFILE 4u  /* diagnostic: per-phase cycle counters in the neighbour kernels */
 #define MGL_F_SERIAL_BUILD 16u /* derive the base structures with the one-wavefront builder only (diagnostic) */
 #define MGL_F_NO_SNAPSHOTS 8u /* do not keep device copies of the all-literal / best base structures:
                               * mgl_sa_begin_epoch then re-derives them from the slab (less memory, slower) */
@@ -154,8 +154,16 @@ int mgl_substrings(mgl_sa* sa, size_t pos, size_t max_len, uint32_t* offsets, ui
  * generate.  diffs (nullable): diff_cap entries per neighbour, ndiffs[j] valid ones. */
 int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* diffs,
                    uint32_t* ndiffs, size_t diff_cap);
-/* Test hook: raw copy of one of the incremental engine's base structures (selector in
- * mgl_api.hip); *bytes receives the size even when the buffer is too small. */
+/* Test / diagnostic hooks (no reference counterpart).  mgl_debug_dump: raw copy of one of the
+ * incremental engine's device structures; *bytes receives the size even when the buffer is too
+ * small.  Selectors: 0 chain offsets, 1 chain lengths, 2 chain positions, 3 chain events,
+ * 4 on-walk bitmap, 5 special bitmap, 6 special-state records, 7 dense checkpoints, 8 chain
+ * capacities, 9 phase-cycle counters (MGL_F_PROFILE), 10 per-step overflow / repair counters,
+ * 11 parallel-builder totals, 12 / 13 match index (bucket offsets / positions), 14 accept-path
+ * counters, 15 pick records, 16 the control block.
+ * mgl_debug_set: key 0 = stop the neighbour kernels after a phase (tools/phase_cost.py), 50 =
+ * stage timing in the accept path; key 1 = make the parallel builder redo every chain segment
+ * serially (exercises its fallback). */
 int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes);
 int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value);
 /* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the

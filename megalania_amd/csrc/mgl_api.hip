@@ -545,7 +545,6 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			(void)best_w; /* measured: one wavefront per workgroup wins although it packs fewer waves (LDS is
 			               * released per workgroup, and neighbour run times have a long tail) */
 			sa->waves_per_block2 = 1;
-			if (getenv("MGL_WAVES_PER_BLOCK")) sa->waves_per_block2 = (uint32_t)atoi(getenv("MGL_WAVES_PER_BLOCK"));
 		}
 		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
 		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;

@@ -564,7 +564,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			c0.nbr_single = 1;
 			HIPCHK(hipMemcpy(sa->base.ctl, &c0, sizeof c0, hipMemcpyHostToDevice));
 		}
-		sa->pick_waves = 1; /* the kernel is built for one wavefront per workgroup (__launch_bounds__(64)) */
+		/* two pick wavefronts share a cost table per workgroup on small inputs (14 instead of 12 per CU);
+		 * on large ones top-K run times vary too much for wavefronts to wait on each other's LDS */
+		sa->pick_waves = getenv("MGL_PICK_WAVES") ? (uint32_t)atoi(getenv("MGL_PICK_WAVES")) : (n <= (1u << 20) ? 2u : 1u);
+		if (sa->pick_waves < 1 || sa->pick_waves > 2) sa->pick_waves = 1;
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
 

@@ -49,6 +49,7 @@ struct ApplyBuf {
 #define MGL_SPACE_CHAIN 0u
 #define MGL_SPACE_SCRATCH 1u
 #define MGL_SPACE_SPAN 2u
+#define MGL_SPACE_SHIFT 3u /* job kind: in-place shift of one chunk of a chain's tail */
 
 __device__ __forceinline__ void bit_write(uint64_t* arr, uint32_t pos, bool on)
 {
@@ -478,22 +479,35 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 		const bool moved = s_newoff != off;
 		const bool tail_stays = !moved && newlen == oldlen;
 		const bool new_sentinel = (s_newtail & 0x10000u) != 0; /* then the tail is the old sentinel alone */
-		const uint32_t save_count = tail_stays ? (kk - k0) : (oldlen + 1u - k0);
 		const uint32_t tail_count = (tail_stays || new_sentinel) ? 0u : (oldlen + 1u - kk);
-		const uint32_t chunk_s = save_count / 512u > MGL_JOB_CHUNK ? (save_count + 511u) / 512u : MGL_JOB_CHUNK;
-		const uint32_t chunk_t = tail_count / 512u > MGL_JOB_CHUNK ? (tail_count + 511u) / 512u : MGL_JOB_CHUNK;
+		/* Three ways to place the old entries:
+		 *  - a chain that moves: everything is read from the old slot and written to the new one (no hazard);
+		 *  - in place, tail not shifting: only the small region [k0, k) is saved and rewritten;
+		 *  - in place, tail shifting by delta (|delta| <= MGL_SUB_CAP): the small region is saved, and the
+		 *    tail moves in one pass of 4 096-entry chunks -- a workgroup loads its chunk into registers,
+		 *    then stores it shifted.  The only entries another chunk's stores can reach before they are
+		 *    loaded are a chunk's last (first) |delta| ones: pass B saves those slivers and the chunk takes
+		 *    them from the save area. */
+		const bool shift = !moved && !tail_stays && tail_count != 0;
+		const int32_t delta = (int32_t)newlen - (int32_t)oldlen;
+		const uint32_t ad = (uint32_t)(delta < 0 ? -delta : delta);
+		const uint32_t small_count = moved ? 0u : (kk - k0);
+		const uint32_t chunk_s = small_count / 512u > MGL_JOB_CHUNK ? (small_count + 511u) / 512u : MGL_JOB_CHUNK;
+		const uint32_t chunk_t = shift ? MGL_JOB_CHUNK : (tail_count / 512u > MGL_JOB_CHUNK ? (tail_count + 511u) / 512u : MGL_JOB_CHUNK);
 		const uint32_t chunk_p = k0 / 512u > MGL_JOB_CHUNK ? (k0 + 511u) / 512u : MGL_JOB_CHUNK;
-		const uint32_t n_save = (save_count + chunk_s - 1u) / chunk_s;
+		const uint32_t n_save = (small_count + chunk_s - 1u) / chunk_s;
 		const uint32_t n_prefix = moved ? (k0 + chunk_p - 1u) / chunk_p : 0u;
 		const uint32_t n_tail = (tail_count + chunk_t - 1u) / chunk_t;
+		const uint32_t n_sliver = shift ? n_tail : 0u;
 		const uint32_t n_small = np - 1u; /* every piece but the tail (always the last one) */
+		const uint32_t scratch_need = small_count + n_sliver * ad;
 		if (tid == 0) {
-			s_job_b = atomicAdd(&ab.hdr[4], n_save + n_prefix);
+			s_job_b = atomicAdd(&ab.hdr[4], n_save + n_prefix + n_sliver);
 			s_job_c = atomicAdd(&ab.hdr[5], n_small + n_tail + (new_sentinel ? 1u : 0u));
 			s_span_base = atomicAdd(&ab.hdr[6], ns + 1u);
-			s_scr_base = atomicAdd(&ab.hdr[7], save_count);
-			if (s_job_b + n_save + n_prefix > ab.job_cap || s_job_c + n_small + n_tail + 1u > ab.job_cap ||
-			    s_span_base + ns + 1u > ab.span_cap || s_scr_base + save_count > ab.scratch_cap)
+			s_scr_base = atomicAdd(&ab.hdr[7], scratch_need);
+			if (s_job_b + n_save + n_prefix + n_sliver > ab.job_cap || s_job_c + n_small + n_tail + 1u > ab.job_cap ||
+			    s_span_base + ns + 1u > ab.span_cap || s_scr_base + scratch_need > ab.scratch_cap || (shift && ad > MGL_SUB_CAP))
 				s_fail = 1;
 		}
 		__syncthreads();
@@ -501,28 +515,38 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 		const uint32_t jb = s_job_b, jc = s_job_c, spb = s_span_base, scb = s_scr_base, noff = s_newoff;
 		for (uint32_t i = tid; i < ns; i += MGL_APPLY_THREADS) { ab.span_pos[spb + i] = s_span_pos[i]; ab.span_ev[spb + i] = s_span_ev[i]; }
 		if (tid == 0 && new_sentinel) { ab.span_pos[spb + ns] = MGL_POS_INF; ab.span_ev[spb + ns] = (uint16_t)(s_newtail & 0x7FFu); }
+		/* pass B */
 		for (uint32_t i = tid; i < n_save; i += MGL_APPLY_THREADS) {
-			const uint32_t at = i * chunk_s, cnt = (save_count - at) < chunk_s ? (save_count - at) : chunk_s;
+			const uint32_t at = i * chunk_s, cnt = (small_count - at) < chunk_s ? (small_count - at) : chunk_s;
 			ab.jobs_b[jb + i] = make_uint4(off + k0 + at, scb + at, cnt, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
 		}
 		for (uint32_t i = tid; i < n_prefix; i += MGL_APPLY_THREADS) {
 			const uint32_t at = i * chunk_p, cnt = (k0 - at) < chunk_p ? (k0 - at) : chunk_p;
 			ab.jobs_b[jb + n_save + i] = make_uint4(off + at, noff + at, cnt, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8));
 		}
+		const Piece tp = s_piece[np - 1u]; /* the tail: { dst, src = k - k0, count = len + 1 - k, from old } */
+		for (uint32_t i = tid; i < n_sliver; i += MGL_APPLY_THREADS) {
+			const uint32_t at = i * chunk_t, cnt = (tail_count - at) < chunk_t ? (tail_count - at) : chunk_t;
+			const uint32_t sl = ad < cnt ? ad : cnt; /* a last chunk shorter than |delta| is a sliver as a whole */
+			const uint32_t from = delta < 0 ? (kk + at + cnt - sl) : (kk + at);
+			ab.jobs_b[jb + n_save + n_prefix + i] = make_uint4(off + from, scb + small_count + i * ad, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
+		}
+		/* pass C */
 		for (uint32_t i = tid; i < n_small; i += MGL_APPLY_THREADS) {
 			const Piece pc = s_piece[i];
 			ab.jobs_c[jc + i] = pc.from_span ? make_uint4(spb + pc.src, noff + k0 + pc.dst, pc.count, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8))
+			                    : moved      ? make_uint4(off + k0 + pc.src, noff + k0 + pc.dst, pc.count, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8))
 			                                 : make_uint4(scb + pc.src, noff + k0 + pc.dst, pc.count, MGL_SPACE_SCRATCH | (MGL_SPACE_CHAIN << 8));
 		}
-		{
-			const Piece tp = s_piece[np - 1u]; /* { dst, src = k - k0, count = len + 1 - k, from old } */
-			for (uint32_t i = tid; i < n_tail; i += MGL_APPLY_THREADS) {
-				const uint32_t at = i * chunk_t, cnt = (tail_count - at) < chunk_t ? (tail_count - at) : chunk_t;
-				ab.jobs_c[jc + n_small + i] = make_uint4(scb + tp.src + at, noff + k0 + tp.dst + at, cnt, MGL_SPACE_SCRATCH | (MGL_SPACE_CHAIN << 8));
-			}
-			if (tid == 0 && new_sentinel)
-				ab.jobs_c[jc + n_small + n_tail] = make_uint4(spb + ns, noff + k0 + tp.dst, 1u, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8));
+		for (uint32_t i = tid; i < n_tail; i += MGL_APPLY_THREADS) {
+			const uint32_t at = i * chunk_t, cnt = (tail_count - at) < chunk_t ? (tail_count - at) : chunk_t;
+			if (shift) /* { first source entry, sliver in the save area, count, kind | |delta| << 8 | sign << 20 } */
+				ab.jobs_c[jc + n_small + i] = make_uint4(off + kk + at, scb + small_count + i * ad, cnt, MGL_SPACE_SHIFT | (ad << 8) | (delta < 0 ? 1u << 20 : 0u));
+			else /* a chain that moves: straight from the old slot */
+				ab.jobs_c[jc + n_small + i] = make_uint4(off + kk + at, noff + k0 + tp.dst + at, cnt, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8));
 		}
+		if (tid == 0 && new_sentinel)
+			ab.jobs_c[jc + n_small + n_tail] = make_uint4(spb + ns, noff + k0 + tp.dst, 1u, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8));
 		if (tid == 0) {
 			b.ch_len[cx] = newlen;
 			if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
@@ -680,6 +704,35 @@ __global__ void __launch_bounds__(256) k_apply_jobs(Base2 b, const Control* ctl,
 	for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
 		const uint4 job = jobs[j];
 		const uint32_t ss = job.w & 0xFFu, ds = (job.w >> 8) & 0xFFu;
+		if (ss == MGL_SPACE_SHIFT) {
+			/* entries [x, x + z) of the chain pool move by delta; the |delta| entries at the end another
+			 * chunk's stores can reach come from the save area (pass B).  Load everything, then store. */
+			const uint32_t ad = (job.w >> 8) & 0xFFFu, cnt = job.z;
+			const bool left = (job.w >> 20) & 1u;
+			const uint32_t sl = ad < cnt ? ad : cnt;
+			uint32_t rp[MGL_JOB_CHUNK / 256u];
+			uint16_t re[MGL_JOB_CHUNK / 256u];
+#pragma unroll
+			for (uint32_t u = 0; u < MGL_JOB_CHUNK / 256u; u++) {
+				const uint32_t i = u * 256u + threadIdx.x;
+				rp[u] = 0; re[u] = 0;
+				if (i < cnt) {
+					const bool in_sliver = left ? (i >= cnt - sl) : (i < sl);
+					const uint32_t si = left ? (i - (cnt - sl)) : i;
+					rp[u] = in_sliver ? ab.scratch_pos[job.y + si] : b.ch_pos[job.x + i];
+					re[u] = in_sliver ? ab.scratch_ev[job.y + si] : b.ch_ev[job.x + i];
+				}
+			}
+			__syncthreads();
+			const uint32_t to = left ? job.x - ad : job.x + ad;
+#pragma unroll
+			for (uint32_t u = 0; u < MGL_JOB_CHUNK / 256u; u++) {
+				const uint32_t i = u * 256u + threadIdx.x;
+				if (i < cnt) { b.ch_pos[to + i] = rp[u]; b.ch_ev[to + i] = re[u]; }
+			}
+			__syncthreads();
+			continue;
+		}
 		const uint32_t* sp = ss == MGL_SPACE_CHAIN ? b.ch_pos : ss == MGL_SPACE_SCRATCH ? ab.scratch_pos : ab.span_pos;
 		const uint16_t* se = ss == MGL_SPACE_CHAIN ? b.ch_ev : ss == MGL_SPACE_SCRATCH ? ab.scratch_ev : ab.span_ev;
 		uint32_t* dp = ds == MGL_SPACE_CHAIN ? b.ch_pos : ab.scratch_pos;

@@ -541,7 +541,7 @@ template <bool BIG, int MODE>
 __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : (MODE == MGL_NBR_PICK ? 2 : 4))) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
-                                                     BigScratch big, uint4* pickrec)
+                                                     BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end)
 {
 	/* the step picks one of the two forms of the regular launch on the device (k_step_end): split
 	 * while repairs are rare (their second pass costs a lone wavefront's latency), one kernel
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MG
 	if (!BIG && ((MODE == MGL_NBR_FULL) != (form_single != 0))) return;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
+	uint32_t j = j_base + blockIdx.x * (blockDim.x >> 6) + wid; /* [j_base, j_end): the slice of the step this launch covers */
 	uint32_t slot = 0;
 	const unsigned long long t_begin = prof_acc ? __builtin_readcyclecounter() : 0ull;
 	if (BIG) {
@@ -562,7 +562,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MG
 		if (slot >= nflag) return;
 		j = uni(big.todo_in[slot]);
 	}
-	if (j >= K) return;
+	if (j >= K || (!BIG && j >= j_end)) return;
 	/* LDS per wavefront: [journal | context bitmap | union].  The union holds EITHER the model +
 	 * top-K price tables (while the mutation is chosen) OR the change lists (afterwards): the
 	 * lists only start to fill once the mutated packet is known.  A repair that needs another

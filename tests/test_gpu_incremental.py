@@ -271,3 +271,35 @@ def test_parallel_build_serial_segment_path():
     a.set_slab(cur)
     assert int(a.debug_dump(11, np.uint64)[7]) == 0
     a.close()
+
+
+def test_launch_forms_give_one_trajectory(monkeypatch):
+    """The neighbour evaluation runs as two launches (pick + rest, with a second pass), as one kernel,
+    or switches between them on the device (k_step_end): same costs for every neighbour, same
+    trajectory, same final slab -- on full-size c2 through the early burst of repair picks."""
+    data, _ = corpus.config_input("c2")
+    K = 4096
+    monkeypatch.delenv("MGL_NO_SPLIT", raising=False)
+    monkeypatch.delenv("MGL_NO_ADAPT", raising=False)
+    adaptive = binding.SA(data, neighbours_per_step=K)
+    monkeypatch.setenv("MGL_NO_ADAPT", "1")
+    split = binding.SA(data, neighbours_per_step=K)
+    monkeypatch.delenv("MGL_NO_ADAPT")
+    monkeypatch.setenv("MGL_NO_SPLIT", "1")
+    single = binding.SA(data, neighbours_per_step=K)
+    monkeypatch.delenv("MGL_NO_SPLIT")
+    for s in range(75):
+        if s % 5 == 0 or 44 <= s <= 62:
+            ca = adaptive.neighbours(s, want_diffs=False)[0]
+            cs = split.neighbours(s, want_diffs=False)[0]
+            c1 = single.neighbours(s, want_diffs=False)[0]
+            assert (ca == c1).all() and (cs == c1).all(), s
+        sts = [x.run(1) for x in (adaptive, split, single)]
+        for k in ("evaluations", "accepted", "current_cost", "best_cost", "packets", "failed"):
+            assert sts[0][k] == sts[2][k] and sts[1][k] == sts[2][k], (s, k)
+    a, _ = adaptive.current()
+    b, _ = split.current()
+    c, _ = single.current()
+    assert (a == c).all() and (b == c).all()
+    for x in (adaptive, split, single):
+        x.close()

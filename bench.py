@@ -125,7 +125,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
 
-    from megalania_amd import binding, corpus, multi_gpu
+    from megalania_amd import binding, build as _build, corpus, multi_gpu
+
+    if local_rank == 0 and not os.environ.get("MGL_NO_AUTOBUILD"):
+        _build.build_all()  # in-tree native build, no-op when current (there is no CPU search path to fall back to)
+    if dist is not None:
+        dist.barrier()
 
     data, desc = corpus.config_input(args.config, args.size or None)
     n = len(data)

@@ -18,6 +18,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Native pieces are built in-tree (git-ignored): make sure they exist and are current -- a no-op
+    when `python -m megalania_amd.build` / __graft_entry__.build() has already run."""
+    if os.environ.get("MGL_NO_AUTOBUILD"):
+        return
+    from megalania_amd import build as _build
+    _build.build_all()
+
+
 def sha(a) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 

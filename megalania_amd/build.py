@@ -36,8 +36,9 @@ def _stale(target: str, sources) -> bool:
 
 
 def _run(cmd):
-    print("+", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # everything a build says goes to stderr: stdout belongs to the caller (bench.py prints one JSON line there)
+    print("+", " ".join(cmd), file=sys.stderr, flush=True)
+    subprocess.check_call(cmd, stdout=sys.stderr)
 
 
 def hipcc() -> str:

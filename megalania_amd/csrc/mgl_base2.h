@@ -26,7 +26,6 @@
 #define MGL_POS_INF 0xFFFFFFFFu
 #define MGL_CHG_CAP 256u   /* inserted / removed events per neighbour kept in LDS */
 #define MGL_BIG_CAP 8192u   /* the same, per flagged neighbour, in the global scratch of the second pass */
-#define MGL_BIG_SLOTS 512u /* (historic: the second pass now has one scratch slot per neighbour) */
 #ifndef MGL_NBR_WAVES_PER_SIMD
 #define MGL_NBR_WAVES_PER_SIMD 2 /* register budget of the neighbour kernel: 2 -> 256 VGPRs, no scratch; 3 -> 168 VGPRs
                                     but 200 B/lane of scratch (52 MB of spill traffic per launch) for the same speed */

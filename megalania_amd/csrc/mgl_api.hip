@@ -262,11 +262,11 @@ static int launch_apply(mgl_sa* sa)
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
 	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
-	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->snapshots ? 1 : 0, (const uint32_t*)sa->d_counts, sa->adaptive ? 1 : 0);
+	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->snapshots ? 1 : 0, sa->d_counts, sa->adaptive ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
-static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
+static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_counts = true)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
 	if (!sa->incremental) {
@@ -277,7 +277,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override)
 		HIPCHK(hipGetLastError());
 		return MGL_OK;
 	}
-	HIPCHK(hipMemsetAsync(sa->d_counts, 0, 4 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots */
+	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 4 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	if (sa->split_nbr) {
 		/* the step's neighbours in two slices on two streams: while the slowest wavefronts of one
@@ -575,8 +575,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		}
 		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
 		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;
-		HIPCHK(hipMalloc(&sa->d_counts, sizeof(uint32_t) * 4));
-		HIPCHK(hipMemset(sa->d_counts, 0, sizeof(uint32_t) * 4));
+		HIPCHK(hipMalloc(&sa->d_counts, sizeof(uint32_t) * 8)); /* [0..3] live, [4..7] the last finished step's */
+		HIPCHK(hipMemset(sa->d_counts, 0, sizeof(uint32_t) * 8));
 		sa->big.todo_in = sa->d_todo; sa->big.todo_in_count = sa->d_counts; sa->big.spill_ctr = sa->d_counts + 2;
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_PICK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -739,7 +739,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	for (uint64_t s = 0; s < steps; s++) {
 		const bool t = s < timed_steps;
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
-		if ((rc = launch_neighbours(sa, ~0ull))) return rc;
+		if ((rc = launch_neighbours(sa, ~0ull, s == 0 || !(sa->incremental && sa->incremental_apply)))) return rc;
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
 		const bool inc_apply = sa->incremental && sa->incremental_apply;
 		hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
@@ -938,6 +938,7 @@ extern "C" int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs,
 	if (!sa || !costs) return fail(MGL_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(sa->device));
 	int rc = launch_neighbours(sa, global_step);
+	if (rc == MGL_OK && sa->d_counts) HIPCHK(hipMemcpyAsync(sa->d_counts + 4, sa->d_counts, sizeof(uint32_t) * 4, hipMemcpyDeviceToDevice, sa->stream));
 	if (rc) return rc;
 	const size_t K = sa->cfg.neighbours_per_step;
 	HIPCHK(hipMemcpyAsync(costs, sa->nbr.cost, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, sa->stream));
@@ -988,7 +989,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
-	case 10: src = sa->d_counts; sz = sizeof(uint32_t) * 4; break;
+	case 10: src = sa->d_counts + 4; sz = sizeof(uint32_t) * 4; break; /* of the last finished step / mgl_neighbours call */
 	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
 	case 16: src = sa->base.ctl; sz = sizeof(Control); break; /* raw control block */
 	case 15: src = sa->d_pickrec; sz = sa->d_pickrec ? sizeof(uint4) * sa->cfg.neighbours_per_step : 0; break;

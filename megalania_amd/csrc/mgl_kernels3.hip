@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 }
 
 /* decide-only variant of the step's tail: flags for k_build's conditional run are reset there */
-__global__ void k_step_end(Control* ctl, int lazy_best, const uint32_t* counts, int adaptive)
+__global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
 		if (adaptive) {
@@ -623,6 +623,8 @@ __global__ void k_step_end(Control* ctl, int lazy_best, const uint32_t* counts, 
 			else if (ctl->accepted_flag) ctl->best_is_current = 0;
 		}
 		ctl->accepted_flag = 0; ctl->apply_failed = 0;
+		/* the per-step counters: kept for diagnostics in [4..7], cleared for the next step (saves a memset launch) */
+		for (int i = 0; i < 4; i++) { counts[4 + i] = counts[i]; counts[i] = 0; }
 	}
 }
 

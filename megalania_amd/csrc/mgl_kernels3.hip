@@ -97,8 +97,11 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 	wave_sync();
 	const uint32_t t = s_jpos[0], last_j = s_jpos[nd - 1];
 
+	const bool prof = c.diag_stop == 50u;
+	const unsigned long long tw0 = prof ? __builtin_readcyclecounter() : 0ull;
 	mgl_wstate nb = uni_state(base_state_at(b, t));
 	mgl_wstate bs = nb;
+	const unsigned long long tw1 = prof ? __builtin_readcyclecounter() : 0ull;
 	Win win; win.base = 0xFFFFFFFFu; win.pk = 0; win.byte = 0;
 	uint32_t n_ins = 0, n_rem = 0;
 	int32_t dpackets = 0;
@@ -200,6 +203,7 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 			mgl_advance(&bs, btype, bdist, blen);
 		}
 	}
+	const unsigned long long tw2 = prof ? __builtin_readcyclecounter() : 0ull;
 	wave_sync();
 	/* the journal goes into the slab (main.c keeps the mutated slab on accept) */
 	if (lane < nd) b.slab[s_jpos[lane]] = s_jnew[lane];
@@ -225,6 +229,11 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 	if (lane == 0) {
 		ab.hdr[0] = n_ins; ab.hdr[1] = n_rem; ab.hdr[2] = failed ? 0u : nt; ab.hdr[3] = t;
 		ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0;
+		if (prof) { /* diagnostic: cycles of [state lookup, walk, listing] and walk iterations of this accept */
+			const unsigned long long tw3 = __builtin_readcyclecounter();
+			ab.hdr[13] = (uint32_t)(tw1 - tw0); ab.hdr[14] = (uint32_t)(tw2 - tw1);
+			ab.hdr[15] = ((uint32_t)(tw3 - tw2) & 0xFFFFFu) | (guard << 20); /* hdr[8..12] belong to k_apply_chains' stages */
+		}
 		ctl->packets = (uint64_t)((int64_t)ctl->packets + dpackets);
 		ctl->rebuild_cost = ctl->cur_cost; /* exact cost of the new base */
 		if (failed) ctl->apply_failed = 1;

@@ -271,6 +271,8 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	if (lane < nhits) { q = c.bucket_pos[hi - 1u - lane]; nx = c.bucket_nx[hi - 1u - lane]; }
 	if (64u + lane < nhits) { q1 = c.bucket_pos[hi - 65u - lane]; nx1 = c.bucket_nx[hi - 65u - lane]; }
 	if (lane < nhits && nx == x2) __builtin_memcpy(&y, c.data + q + 4, 8);
+	uint32_t lim32;
+	{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
 	for (uint32_t hb = 0; hb < nhits; hb += 64) {
 		bool have = hb + lane < nhits;
 		if (hb + 64u + lane < nhits && nx1 == x2) __builtin_memcpy(&y1, c.data + q1 + 4, 8);
@@ -328,15 +330,15 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 			minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
 		}
 		/* one table read decides for most hits: even the cheapest conceivable price at the longest
-		 * length this hit offers does not reach the current K-th best */
-		const uint64_t thr0 = topk_threshold(t);
-		const uint64_t lim0 = thr0 == MGL_INVALID_COST ? ~0ull : (thr0 >> 44) + 1ull;
+		 * length this hit offers does not reach the current K-th best.  lim32 = (K-th best cost + 1),
+		 * kept across batches and refreshed after offers; costs are < 2^20 and lengths <= 273, so the
+		 * products fit 32 bits (0xFFFFFFFF = no K-th best yet) */
 		uint32_t lb = 0;
 		if (have) {
 			const uint32_t lb_m = hdr_match + minlen_m + lbslot[slot];
 			const uint32_t lb_r = hdr_lr_min + minlen_r;
 			lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
-			if ((uint64_t)lb >= lim0 * L && c.diag_stop != 38 && c.diag_stop != 34) have = false;
+			if (lim32 != 0xFFFFFFFFu && lb >= lim32 * L && c.diag_stop != 38 && c.diag_stop != 34) have = false;
 		}
 		if (!__ballot(have)) continue;
 		if (have) {
@@ -358,10 +360,11 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 		while (__ballot(have)) {
 			const uint64_t thr = topk_threshold(t);
 			/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
-			const uint64_t lim = thr == MGL_INVALID_COST ? ~0ull : (thr >> 44) + 1ull;
+			const bool nolim = thr == MGL_INVALID_COST;
+			const uint32_t lim = nolim ? 0u : (uint32_t)(thr >> 44) + 1u;
 			uint64_t cand = MGL_INVALID_COST;
 			while (have) {
-				if ((uint64_t)lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
+				if (!nolim && lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
 				uint32_t perp, ctype, cdist;
 				if (kind == 0) {
 					const uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
@@ -377,13 +380,14 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 				uint32_t nk = kind + 1;
 				while (nk <= 4 && !((repmask >> (nk - 1)) & 1u)) nk++;
 				if (nk <= 4) kind = nk; else { kind = 0; len--; if (len < 2) have = false; }
-				if ((uint64_t)perp >= lim * clen || c.diag_stop == 36) continue;
+				if ((!nolim && perp >= lim * clen) || c.diag_stop == 36) continue;
 				if (ctype == inc_type && clen == inc_len && cdist == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
 				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(cq + 1) << 12) | ((uint64_t)clen << 3) | ckind);
 				if (key < thr) { cand = key; break; }
 			}
 			if (c.diag_stop != 35) topk_offer(t, cand, lane, c.diag_stop != 80);
 		}
+		{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
 	}
 }
 

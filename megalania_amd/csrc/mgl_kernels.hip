@@ -271,6 +271,17 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	if (lane < nhits) { q = c.bucket_pos[hi - 1u - lane]; nx = c.bucket_nx[hi - 1u - lane]; }
 	if (64u + lane < nhits) { q1 = c.bucket_pos[hi - 65u - lane]; nx1 = c.bucket_nx[hi - 65u - lane]; }
 	if (lane < nhits && nx == x2) __builtin_memcpy(&y, c.data + q + 4, 8);
+	/* a hit can only be a LONG_REP candidate if one of the four rep distances points at a position
+	 * of this bucket: decided once per query (four scalar byte pairs), not four compares per hit */
+	bool any_rep = false;
+	{
+		const uint32_t b0 = bigram >> 8, b1 = bigram & 0xFFu;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) {
+			const uint32_t dk = mgl_dist_at(&w.st, k);
+			if (dk < pos) { const uint32_t rq = pos - dk - 1u; any_rep = any_rep || (c.data[rq] == b0 && c.data[rq + 1] == b1); }
+		}
+	}
 	uint32_t lim32;
 	{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
 	for (uint32_t hb = 0; hb < nhits; hb += 64) {
@@ -306,8 +317,9 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 				}
 			}
 			if (L > maxlen) L = maxlen;
-			repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
-			          (w.st.dists[3] == d ? 8u : 0u);
+			if (any_rep)
+				repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
+				          (w.st.dists[3] == d ? 8u : 0u);
 			slot = d;
 			if (d >= 4) {
 				const uint32_t nlow = mgl_msb32(d) - 2;

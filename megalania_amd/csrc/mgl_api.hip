@@ -65,6 +65,8 @@ struct mgl_sa {
 	uint32_t* d_bucket_off;
 	uint32_t* d_bucket_pos;
 	uint16_t* d_bucket_nx;
+	uint32_t* d_quad_pos;
+	uint16_t* d_quad_nx;
 	uint16_t* d_cost_tbl;
 	BaseMem base, scratch;
 	mgl_pk* d_best;
@@ -344,7 +346,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	if (!sa) return;
 	(void)hipSetDevice(sa->device);
 	if (sa->stream) (void)hipStreamSynchronize(sa->stream);
-	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_bucket_nx); dfree(sa->d_cost_tbl);
+	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_bucket_nx); dfree(sa->d_quad_pos); dfree(sa->d_quad_nx); dfree(sa->d_cost_tbl);
 	free_base(sa->base); free_base(sa->scratch);
 	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
@@ -398,15 +400,18 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&sa->d_bucket_off, sizeof(uint32_t) * 65537));
 		HIPCHK(hipMalloc(&sa->d_bucket_pos, sizeof(uint32_t) * (n ? n : 1)));
 		HIPCHK(hipMalloc(&sa->d_bucket_nx, sizeof(uint16_t) * (n ? n : 1)));
+		HIPCHK(hipMalloc(&sa->d_quad_pos, sizeof(uint32_t) * (n ? n : 1)));
+		HIPCHK(hipMalloc(&sa->d_quad_nx, sizeof(uint16_t) * (n ? n : 1)));
 		if (m == 0) HIPCHK(hipMemset(sa->d_bucket_off, 0, sizeof(uint32_t) * 65537));
 		else {
 			const uint32_t nblk = (m + MGL_IX_ITEMS - 1) / MGL_IX_ITEMS;
 			uint32_t *tmp = nullptr, *matrix = nullptr;
 			HIPCHK(hipMalloc(&tmp, sizeof(uint32_t) * m));
 			HIPCHK(hipMalloc(&matrix, sizeof(uint32_t) * 256 * (size_t)nblk));
-			for (int pass = 0; pass < 2; pass++) {
-				const uint32_t* in = pass == 0 ? nullptr : tmp;
-				uint32_t* out = pass == 0 ? tmp : sa->d_bucket_pos;
+			/* bigram order: by data[p + 1], then data[p] */
+			for (int pass = 1; pass >= 0; pass--) {
+				const uint32_t* in = pass == 1 ? nullptr : tmp;
+				uint32_t* out = pass == 1 ? tmp : sa->d_bucket_pos;
 				hipLaunchKernelGGL(ix_count, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, m, pass, matrix, nblk);
 				hipLaunchKernelGGL(ix_scan, dim3(1), dim3(1024), 0, sa->stream, matrix, 256u * nblk);
 				hipLaunchKernelGGL(ix_scatter, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, out, m, pass,
@@ -415,7 +420,18 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			hipLaunchKernelGGL(ix_offsets, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
 			                   (const uint32_t*)sa->d_bucket_pos, m, sa->d_bucket_off);
 			hipLaunchKernelGGL(ix_next2, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
-			                   (const uint32_t*)sa->d_bucket_pos, m, sa->d_bucket_nx);
+			                   (const uint32_t*)sa->d_bucket_pos, m, sa->d_bucket_nx, 0);
+			/* four-byte order: by data[p + 3], data[p + 2], data[p + 1], data[p] (ping-pong tmp <-> quad_pos) */
+			for (int pass = 3; pass >= 0; pass--) {
+				const uint32_t* in = pass == 3 ? nullptr : ((pass & 1) ? (const uint32_t*)sa->d_quad_pos : (const uint32_t*)tmp);
+				uint32_t* out = (pass & 1) ? tmp : sa->d_quad_pos;
+				hipLaunchKernelGGL(ix_count, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, m, pass, matrix, nblk);
+				hipLaunchKernelGGL(ix_scan, dim3(1), dim3(1024), 0, sa->stream, matrix, 256u * nblk);
+				hipLaunchKernelGGL(ix_scatter, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, out, m, pass,
+				                   (const uint32_t*)matrix, nblk);
+			}
+			hipLaunchKernelGGL(ix_next2, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
+			                   (const uint32_t*)sa->d_quad_pos, m, sa->d_quad_nx, 1);
 			hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(sa->stream);
 			(void)hipFree(tmp); (void)hipFree(matrix);
 			HIPCHK(e1); HIPCHK(e2);
@@ -425,7 +441,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMemcpy(sa->d_cost_tbl, k_cost_table, sizeof(k_cost_table), hipMemcpyHostToDevice));
 
 	sa->ctx.data = sa->d_data; sa->ctx.n = (uint32_t)n;
-	sa->ctx.bucket_off = sa->d_bucket_off; sa->ctx.bucket_pos = sa->d_bucket_pos; sa->ctx.bucket_nx = sa->d_bucket_nx;
+	sa->ctx.bucket_off = sa->d_bucket_off; sa->ctx.bucket_pos = sa->d_bucket_pos; sa->ctx.bucket_nx = sa->d_bucket_nx; sa->ctx.quad_pos = sa->d_quad_pos; sa->ctx.quad_nx = sa->d_quad_nx;
 	sa->ctx.cost_tbl = sa->d_cost_tbl; sa->ctx.L = L;
 	sa->ctx.dict_limit = sa->cfg.dict_limit; sa->ctx.max_scan = sa->cfg.max_bucket_scan; sa->ctx.top_k = sa->cfg.top_k;
 
@@ -993,6 +1009,8 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
 	case 16: src = sa->base.ctl; sz = sizeof(Control); break; /* raw control block */
 	case 15: src = sa->d_pickrec; sz = sa->d_pickrec ? sizeof(uint4) * sa->cfg.neighbours_per_step : 0; break;
+	case 18: src = sa->d_quad_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 19: src = sa->d_quad_nx; sz = sizeof(uint16_t) * (sa->n - 1); break;
 	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
 	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */

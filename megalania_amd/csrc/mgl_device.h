@@ -30,6 +30,8 @@ struct DevCtx {
 	const uint32_t* bucket_off; /* 65537 */
 	const uint32_t* bucket_pos; /* n-1 positions, ascending inside each bigram bucket */
 	const uint16_t* bucket_nx;  /* per entry of bucket_pos: data[p + 2] | data[p + 3] << 8 */
+	const uint32_t* quad_pos;   /* the same positions ordered by (data[p..p+3], p): inside a bigram bucket, runs of equal next-two-bytes */
+	const uint16_t* quad_nx;    /* per entry of quad_pos: data[p + 2] << 8 | data[p + 3] (ascending inside a bucket) */
 	const uint16_t* cost_tbl;   /* 2048 x u16 */
 	mgl_layout L;
 	uint32_t dict_limit;

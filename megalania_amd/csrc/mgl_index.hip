@@ -9,15 +9,21 @@
  * digits with ballots, so equal keys keep their position order.  bucket_off is then read off the
  * sorted keys.  The dictionary window (dict_limit) is applied at query time by a search inside
  * the bucket (bucket_lower_bound, mgl_kernels.hip), so the index itself is window-independent.
+ * A second order of the same positions -- by the four bytes at the position, then by position
+ * (two more passes in front) -- groups, inside every bigram bucket, the entries that agree on
+ * the next two bytes as well: a top-K query reads its >= 4-byte matches as one contiguous,
+ * position-ordered run of that array instead of finding them among all the bucket's entries.
  */
 #include "mgl_device.h"
 
 #define MGL_IX_ITEMS 4096u /* per wavefront */
 
+/* `pass` = byte offset from the position that this counting pass sorts by; `in` = the order produced
+ * by the previous pass (nullptr: positions in their natural order) */
 __device__ __forceinline__ uint32_t ix_digit(const uint8_t* data, const uint32_t* in, uint32_t idx, int pass, uint32_t& pos)
 {
-	pos = pass == 0 ? idx : in[idx];
-	return pass == 0 ? data[pos + 1] : data[pos];
+	pos = in ? in[idx] : idx;
+	return data[pos + (uint32_t)pass];
 }
 
 __global__ void __launch_bounds__(64) ix_count(const uint8_t* data, const uint32_t* in, uint32_t m, int pass, uint32_t* matrix, uint32_t nblk)
@@ -107,11 +113,14 @@ __global__ void __launch_bounds__(256) ix_offsets(const uint8_t* data, const uin
 	for (uint32_t k = prev; k <= key; k++) bucket_off[k] = j; /* empty buckets in between start here too */
 }
 
-/* the two bytes after each indexed bigram, in bucket order (the input is zero padded past its end) */
-__global__ void __launch_bounds__(256) ix_next2(const uint8_t* data, const uint32_t* sorted, uint32_t m, uint16_t* nx)
+/* the two bytes after each indexed bigram, in the order of `sorted` (the input is zero padded past its
+ * end).  big_endian = 0: data[p+2] | data[p+3] << 8 (bucket_nx, only compared for equality);
+ * big_endian = 1: data[p+2] << 8 | data[p+3] (quad_nx: ascending inside a bucket, searchable) */
+__global__ void __launch_bounds__(256) ix_next2(const uint8_t* data, const uint32_t* sorted, uint32_t m, uint16_t* nx, int big_endian)
 {
 	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= m) return;
 	const uint32_t p = sorted[j];
-	nx[j] = (uint16_t)((uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8));
+	const uint32_t a = data[p + 2], b = data[p + 3];
+	nx[j] = (uint16_t)(big_endian ? ((a << 8) | b) : (a | (b << 8)));
 }

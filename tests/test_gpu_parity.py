@@ -256,6 +256,16 @@ def test_match_index_built_on_device(cfg, size):
     got_pos = sa.debug_dump(13, np.uint32)
     assert (got_off == want_off).all()
     assert (got_pos == want_pos).all()
+    # the second order of the same positions: by the four bytes at the position (zero padded), then by position
+    dp = np.concatenate([d, np.zeros(4, dtype=np.uint32)])
+    m = len(d) - 1
+    idx = np.arange(m)
+    key4 = (dp[idx] << 24) | (dp[idx + 1] << 16) | (dp[idx + 2] << 8) | dp[idx + 3]
+    want_quad = np.argsort(key4, kind="stable").astype(np.uint32)
+    got_quad = sa.debug_dump(18, np.uint32)
+    got_qnx = sa.debug_dump(19, np.uint16)
+    assert (got_quad == want_quad).all()
+    assert (got_qnx == (key4[want_quad] & 0xFFFF).astype(np.uint16)).all()
     sa.close()
 
 

@@ -20,7 +20,7 @@
 #define MGL_CKPT_SHIFT 10u          /* one prefix checkpoint per 1024 input bytes */
 #define MGL_MAX_DIFFS 64u           /* journal capacity per neighbour */
 #define MGL_MAX_TOPK 32u
-#define MGL_PRICE_WORDS 1008u         /* top-K price tables per wavefront (u32): 2x272 lengths, 4x64 slots, 128 tails, 16 align, 64 slot bounds */
+#define MGL_PRICE_WORDS 1072u         /* top-K price tables per wavefront (u32): 2x272 lengths, 4x64 slots, 128 tails, 16 align, 64 slot bounds, 64 suffix minima */
 #define MGL_SEQ_MASK ((1ull << 44) - 1ull)
 #define MGL_INVALID_COST (~0ull)
 

@@ -143,6 +143,24 @@ __device__ __forceinline__ uint32_t bucket_lower_bound(const uint32_t* bp, uint3
 	return a;
 }
 
+/* the same search over the big-endian next-two-bytes column of the four-byte order */
+__device__ __forceinline__ uint32_t nx_lower_bound(const uint16_t* a, uint32_t lo, uint32_t hi, uint32_t x, uint32_t lane)
+{
+	while (hi > lo) {
+		const uint32_t span = hi - lo, step = (span + 63u) / 64u;
+		const uint32_t idx = lo + lane * step;
+		const bool ge = idx >= hi ? true : ((uint32_t)a[idx] >= x);
+		const unsigned long long m = __ballot(ge);
+		const int f = m ? __ffsll((long long)m) - 1 : 64;
+		if (f == 0) break;
+		const uint32_t na = lo + (uint32_t)(f - 1) * step + 1u;
+		uint32_t nb = lo + (uint32_t)f * step;
+		if (nb > hi) nb = hi;
+		lo = na; hi = nb;
+	}
+	return lo;
+}
+
 /* top_k_packet_finder_find (top_k_packet_finder.c:120-125): enumerate every legal next
  * packet at the walk's state, cost each from the adapted model (cost = perplexity/length,
  * :115-116), keep the k best.  Order-independent ("canonical") selection: better = lower
@@ -194,6 +212,7 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	wave_sync();
 	/* per distance slot: the least a distance in that slot can cost in any length context (pruning bound) */
 	uint32_t* lbslot = lencost + 944;
+	uint32_t* sufmin = lencost + 1008;
 	{
 		const uint32_t slot = lane;
 		uint32_t m = slotcost[slot];
@@ -204,6 +223,13 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 		/* direct bits + at least the cheapest align nibble; the reverse-tree tails of nearer slots count as 0 */
 		if (slot >= 14) m += (((slot >> 1) - 5u) << 11) + amin;
 		lbslot[slot] = m;
+		/* sufmin[s] = the least of lbslot[s..63] */
+		uint32_t sm = m;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t tdn = (uint32_t)__shfl_down((int)sm, o, 64);
+			if ((int)lane + o < 64) sm = tdn < sm ? tdn : sm;
+		}
+		sufmin[slot] = sm;
 	}
 	wave_sync();
 	if (c.diag_stop == 31) return;
@@ -261,16 +287,27 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	 * enumeration order), so the K-th best is close to final after the first batch and almost
 	 * every farther hit is turned away by the lower-bound test alone */
 	const uint32_t nhits = hi - lo;
-	/* Software pipeline over batches of 64 hits: the bucket entries of batch i+2 and the first
-	 * eight input bytes (offsets 4..11) of the long matches of batch i+1 are in flight while batch i
-	 * is priced. */
+	/* Two sources feed the pricing code, nearest entries first in both.
+	 *   long:  the run of the four-byte order (quad_pos) whose entries share the target's next two
+	 *          bytes as well -- exactly the hits that match >= 4 bytes, positions ascending, cut to the
+	 *          same window; their first eight further input bytes are gathered one batch ahead.
+	 *   short: the bucket itself (bucket_pos), entries of that run skipped: hits of length 2 or 3,
+	 *          sized from bucket_nx alone.  Their price grows with the distance slot, so the scan stops
+	 *          at the first batch whose nearest entry cannot reach the K-th best any more even with the
+	 *          cheapest length and the cheapest slot from there on (sufmin). */
 	uint64_t x4;
 	__builtin_memcpy(&x4, c.data + pos + 4, 8);
-	uint32_t q = 0, nx = 0, q1 = 0, nx1 = 0, q2 = 0, nx2 = 0;
-	uint64_t y = 0, y1 = 0;
-	if (lane < nhits) { q = c.bucket_pos[hi - 1u - lane]; nx = c.bucket_nx[hi - 1u - lane]; }
-	if (64u + lane < nhits) { q1 = c.bucket_pos[hi - 65u - lane]; nx1 = c.bucket_nx[hi - 65u - lane]; }
-	if (lane < nhits && nx == x2) __builtin_memcpy(&y, c.data + q + 4, 8);
+	const uint32_t x2be = ((uint32_t)c.data[pos + 2] << 8) | (uint32_t)c.data[pos + 3];
+	uint32_t qlo, qhi;
+	{
+		const uint32_t b_lo = c.bucket_off[bigram];
+		const uint32_t qa = nx_lower_bound(c.quad_nx, b_lo, end, x2be, lane);
+		const uint32_t qb = x2be == 0xFFFFu ? end : nx_lower_bound(c.quad_nx, qa, end, x2be + 1u, lane);
+		qhi = bucket_lower_bound(c.quad_pos, qa, qb, pos, lane);
+		qlo = qhi;
+		if (nhits != 0) qlo = bucket_lower_bound(c.quad_pos, qa, qhi, c.bucket_pos[lo], lane); /* the bucket scan's window */
+	}
+	const uint32_t minlen_short = lencost[0] < lencost[1] ? lencost[0] : lencost[1];
 	/* a hit can only be a LONG_REP candidate if one of the four rep distances points at a position
 	 * of this bucket: decided once per query (four scalar byte pairs), not four compares per hit */
 	bool any_rep = false;
@@ -284,122 +321,145 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	}
 	uint32_t lim32;
 	{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
-	for (uint32_t hb = 0; hb < nhits; hb += 64) {
-		bool have = hb + lane < nhits;
-		if (hb + 64u + lane < nhits && nx1 == x2) __builtin_memcpy(&y1, c.data + q1 + 4, 8);
-		if (hb + 128u + lane < nhits) { q2 = c.bucket_pos[hi - 1u - (hb + 128u + lane)]; nx2 = c.bucket_nx[hi - 1u - (hb + 128u + lane)]; }
-		const uint32_t cq = q, cnx = nx;
-		const uint64_t cy = y;
-		q = q1; nx = nx1; y = y1; q1 = q2; nx1 = nx2; /* the waits these moves imply come after the pricing below */
-		if (c.diag_stop == 37) { t.key ^= (uint64_t)(cq + cnx); continue; }
-		uint32_t d = 0, L = 0, repmask = 0, slot = 0;
-		uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, tail = 0;
-		if (have) {
-			d = pos - cq - 1;
-			/* match extension, substring_enumerator.c:99-103: bytes 2 and 3 from the index, then eight
-			 * bytes per step from the input (zero-padded past its end; global memory takes unaligned
-			 * 8-byte loads) */
-			const uint32_t df2 = cnx ^ x2;
-			L = (df2 & 0xFFu) ? 2u : (df2 >> 8) ? 3u : 4u;
-			if (L == 4 && c.diag_stop != 38) {
-				const uint64_t df4 = x4 ^ cy;
-				if (df4) L += ((uint32_t)__ffsll((long long)df4) - 1u) >> 3;
-				else {
-					L = 12;
-					while (L < maxlen) {
-						uint64_t x, yy;
-						__builtin_memcpy(&x, c.data + pos + L, 8);
-						__builtin_memcpy(&yy, c.data + cq + L, 8);
-						const uint64_t df = x ^ yy;
-						if (df) { L += ((uint32_t)__ffsll((long long)df) - 1u) >> 3; break; }
-						L += 8;
+	for (uint32_t ph = 0; ph < 2; ph++) {
+		const bool longp = ph == 0;
+		const uint32_t* spos = longp ? c.quad_pos : c.bucket_pos;
+		const uint16_t* snx = longp ? c.quad_nx : c.bucket_nx;
+		const uint32_t top = longp ? qhi : hi, cnt = longp ? qhi - qlo : nhits;
+		uint32_t q = 0, nx = 0, q1 = 0, nx1 = 0, q2 = 0, nx2 = 0;
+		uint64_t y = 0, y1 = 0;
+		if (lane < cnt) { q = spos[top - 1u - lane]; nx = snx[top - 1u - lane]; }
+		if (64u + lane < cnt) { q1 = spos[top - 65u - lane]; nx1 = snx[top - 65u - lane]; }
+		if (longp && lane < cnt) __builtin_memcpy(&y, c.data + q + 4, 8);
+		for (uint32_t hb = 0; hb < cnt; hb += 64) {
+			bool have = hb + lane < cnt;
+			if (longp && hb + 64u + lane < cnt) __builtin_memcpy(&y1, c.data + q1 + 4, 8);
+			if (hb + 128u + lane < cnt) { q2 = spos[top - 1u - (hb + 128u + lane)]; nx2 = snx[top - 1u - (hb + 128u + lane)]; }
+			const uint32_t cq = q, cnx = nx;
+			const uint64_t cy = y;
+			q = q1; nx = nx1; y = y1; q1 = q2; nx1 = nx2;
+			if (c.diag_stop == 37) { t.key ^= (uint64_t)(cq + cnx); continue; }
+			if (!longp) {
+				/* lane 0 holds the nearest entry of this batch */
+				const uint32_t dn = pos - rdlane(cq, 0) - 1u;
+				uint32_t sn = dn;
+				if (dn >= 4) { const uint32_t nl = mgl_msb32(dn) - 2; sn = nl * 2 + (dn >> nl); }
+				if (!any_rep && lim32 != 0xFFFFFFFFu && hdr_match + minlen_short + sufmin[sn] >= lim32 * 3u && c.diag_stop != 38 && c.diag_stop != 34) break;
+				if (cnx == x2) have = false; /* a >= 4-byte match: priced from the long run */
+			}
+			uint32_t d = 0, L = 0, repmask = 0, slot = 0;
+			uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, tail = 0;
+			if (have) {
+				d = pos - cq - 1;
+				/* match extension, substring_enumerator.c:99-103: bytes 2 and 3 from the index, then eight
+				 * bytes per step from the input (zero-padded past its end; global memory takes unaligned
+				 * 8-byte loads) */
+				if (longp) {
+					/* four bytes match by construction of the run; eight more arrived with the entry */
+					L = 4;
+					if (c.diag_stop != 38) {
+						const uint64_t df4 = x4 ^ cy;
+						if (df4) L += ((uint32_t)__ffsll((long long)df4) - 1u) >> 3;
+						else {
+							L = 12;
+							while (L < maxlen) {
+								uint64_t x, yy;
+								__builtin_memcpy(&x, c.data + pos + L, 8);
+								__builtin_memcpy(&yy, c.data + cq + L, 8);
+								const uint64_t df = x ^ yy;
+								if (df) { L += ((uint32_t)__ffsll((long long)df) - 1u) >> 3; break; }
+								L += 8;
+							}
+						}
 					}
-				}
-			}
-			if (L > maxlen) L = maxlen;
-			if (any_rep)
-				repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
-				          (w.st.dists[3] == d ? 8u : 0u);
-			slot = d;
-			if (d >= 4) {
-				const uint32_t nlow = mgl_msb32(d) - 2;
-				slot = nlow * 2 + (d >> nlow);
-			}
-		}
-		if (!high_ready && __ballot(have && L >= 18)) {
-			for (uint32_t l = 18 + lane; l <= MGL_MAX_MATCH; l += 64) {
-				lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
-				lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
-			}
-			high_ready = true;
-			wave_sync();
-			uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
-			for (uint32_t l = 16 + lane; l < 272; l += 64) { a = lencost[l] < a ? lencost[l] : a; b = lencost[272 + l] < b ? lencost[272 + l] : b; }
-			for (int o = 32; o > 0; o >>= 1) {
-				const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, 64), b2 = (uint32_t)__shfl_xor((int)b, o, 64);
-				a = a2 < a ? a2 : a; b = b2 < b ? b2 : b;
-			}
-			minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
-		}
-		/* one table read decides for most hits: even the cheapest conceivable price at the longest
-		 * length this hit offers does not reach the current K-th best.  lim32 = (K-th best cost + 1),
-		 * kept across batches and refreshed after offers; costs are < 2^20 and lengths <= 273, so the
-		 * products fit 32 bits (0xFFFFFFFF = no K-th best yet) */
-		uint32_t lb = 0;
-		if (have) {
-			const uint32_t lb_m = hdr_match + minlen_m + lbslot[slot];
-			const uint32_t lb_r = hdr_lr_min + minlen_r;
-			lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
-			if (lim32 != 0xFFFFFFFFu && lb >= lim32 * L && c.diag_stop != 38 && c.diag_stop != 34) have = false;
-		}
-		if (!__ballot(have)) continue;
-		if (have) {
-			/* distance price per length context from the tables */
-			if (d >= 4) {
-				const uint32_t nlow = mgl_msb32(d) - 2;
-				tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
-			}
-			s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
-		}
-		if (c.diag_stop == 34 || c.diag_stop == 38) { t.key ^= (uint64_t)(s0 + s1 + s2 + s3 + tail + L); continue; }
-		/* Candidates of a hit: for every length 2..L the MATCH and a LONG_REP per rep slot that holds
-		 * this distance (packet_enumerator.c:48-54).  The selection is order-independent, so each lane
-		 * walks its hit from the longest length down (the cheapest per byte first, which tightens the
-		 * threshold at once) and stops as soon as even a lower bound of the price cannot beat the
-		 * current K-th best any more.  The exact perp/len division is only done for candidates that
-		 * pass the multiply test. */
-		uint32_t len = L, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
-		while (__ballot(have)) {
-			const uint64_t thr = topk_threshold(t);
-			/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
-			const bool nolim = thr == MGL_INVALID_COST;
-			const uint32_t lim = nolim ? 0u : (uint32_t)(thr >> 44) + 1u;
-			uint64_t cand = MGL_INVALID_COST;
-			while (have) {
-				if (!nolim && lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
-				uint32_t perp, ctype, cdist;
-				if (kind == 0) {
-					const uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
-					perp = hdr_match + lencost[len - 2] + sc + tail;
-					ctype = MGL_MATCH; cdist = d;
 				} else {
-					const uint32_t i = kind - 1;
-					perp = (i == 0 ? hdr_lr0 : i == 1 ? hdr_lr1 : i == 2 ? hdr_lr2 : hdr_lr3) + lencost[272 + len - 2];
-					ctype = MGL_LONG_REP; cdist = i;
+					L = ((cnx ^ x2) & 0xFFu) ? 2u : 3u; /* the third byte differs, or only the fourth */
 				}
-				const uint32_t clen = len, ckind = kind;
-				/* next candidate of this hit */
-				uint32_t nk = kind + 1;
-				while (nk <= 4 && !((repmask >> (nk - 1)) & 1u)) nk++;
-				if (nk <= 4) kind = nk; else { kind = 0; len--; if (len < 2) have = false; }
-				if ((!nolim && perp >= lim * clen) || c.diag_stop == 36) continue;
-				if (ctype == inc_type && clen == inc_len && cdist == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
-				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(cq + 1) << 12) | ((uint64_t)clen << 3) | ckind);
-				if (key < thr) { cand = key; break; }
+				if (L > maxlen) L = maxlen;
+				if (any_rep)
+					repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
+					          (w.st.dists[3] == d ? 8u : 0u);
+				slot = d;
+				if (d >= 4) {
+					const uint32_t nlow = mgl_msb32(d) - 2;
+					slot = nlow * 2 + (d >> nlow);
+				}
 			}
-			if (c.diag_stop != 35) topk_offer(t, cand, lane, c.diag_stop != 80);
+			if (!high_ready && __ballot(have && L >= 18)) {
+				for (uint32_t l = 18 + lane; l <= MGL_MAX_MATCH; l += 64) {
+					lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
+					lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
+				}
+				high_ready = true;
+				wave_sync();
+				uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
+				for (uint32_t l = 16 + lane; l < 272; l += 64) { a = lencost[l] < a ? lencost[l] : a; b = lencost[272 + l] < b ? lencost[272 + l] : b; }
+				for (int o = 32; o > 0; o >>= 1) {
+					const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, 64), b2 = (uint32_t)__shfl_xor((int)b, o, 64);
+					a = a2 < a ? a2 : a; b = b2 < b ? b2 : b;
+				}
+				minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
+			}
+			/* one table read decides for most hits: even the cheapest conceivable price at the longest
+			 * length this hit offers does not reach the current K-th best.  lim32 = (K-th best cost + 1),
+			 * kept across batches and refreshed after offers; costs are < 2^20 and lengths <= 273, so the
+			 * products fit 32 bits (0xFFFFFFFF = no K-th best yet) */
+			uint32_t lb = 0;
+			if (have) {
+				const uint32_t lb_m = hdr_match + minlen_m + lbslot[slot];
+				const uint32_t lb_r = hdr_lr_min + minlen_r;
+				lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
+				if (lim32 != 0xFFFFFFFFu && lb >= lim32 * L && c.diag_stop != 38 && c.diag_stop != 34) have = false;
+			}
+			if (!__ballot(have)) continue;
+			if (have) {
+				/* distance price per length context from the tables */
+				if (d >= 4) {
+					const uint32_t nlow = mgl_msb32(d) - 2;
+					tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
+				}
+				s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
+			}
+			if (c.diag_stop == 34 || c.diag_stop == 38) { t.key ^= (uint64_t)(s0 + s1 + s2 + s3 + tail + L); continue; }
+			/* Candidates of a hit: for every length 2..L the MATCH and a LONG_REP per rep slot that holds
+			 * this distance (packet_enumerator.c:48-54).  The selection is order-independent, so each lane
+			 * walks its hit from the longest length down (the cheapest per byte first, which tightens the
+			 * threshold at once) and stops as soon as even a lower bound of the price cannot beat the
+			 * current K-th best any more.  The exact perp/len division is only done for candidates that
+			 * pass the multiply test. */
+			uint32_t len = L, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
+			while (__ballot(have)) {
+				const uint64_t thr = topk_threshold(t);
+				/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
+				const bool nolim = thr == MGL_INVALID_COST;
+				const uint32_t lim = nolim ? 0u : (uint32_t)(thr >> 44) + 1u;
+				uint64_t cand = MGL_INVALID_COST;
+				while (have) {
+					if (!nolim && lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
+					uint32_t perp, ctype, cdist;
+					if (kind == 0) {
+						const uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
+						perp = hdr_match + lencost[len - 2] + sc + tail;
+						ctype = MGL_MATCH; cdist = d;
+					} else {
+						const uint32_t i = kind - 1;
+						perp = (i == 0 ? hdr_lr0 : i == 1 ? hdr_lr1 : i == 2 ? hdr_lr2 : hdr_lr3) + lencost[272 + len - 2];
+						ctype = MGL_LONG_REP; cdist = i;
+					}
+					const uint32_t clen = len, ckind = kind;
+					/* next candidate of this hit */
+					uint32_t nk = kind + 1;
+					while (nk <= 4 && !((repmask >> (nk - 1)) & 1u)) nk++;
+					if (nk <= 4) kind = nk; else { kind = 0; len--; if (len < 2) have = false; }
+					if ((!nolim && perp >= lim * clen) || c.diag_stop == 36) continue;
+					if (ctype == inc_type && clen == inc_len && cdist == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
+					const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(cq + 1) << 12) | ((uint64_t)clen << 3) | ckind);
+					if (key < thr) { cand = key; break; }
+				}
+				if (c.diag_stop != 35) topk_offer(t, cand, lane, c.diag_stop != 80);
+			}
+			{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
 		}
-		{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
 	}
 }
 

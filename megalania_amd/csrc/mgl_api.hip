@@ -92,6 +92,7 @@ struct mgl_sa {
 	size_t b2_bytes;
 	BigScratch big;
 	uint32_t* d_todo2;
+	uint4* d_pickstate;     /* 2 K: target, RNG position and walk state at the target (first half -> second half) */
 	uint4* d_pickrec;       /* K: picked packet, RNG position, ok flag (first half -> second half of the neighbour evaluation) */
 	bool split_nbr, adaptive; /* adaptive: the device switches between the split and the one-kernel form step by step */
 	uint32_t* d_counts;     /* [0] first-pass overflow count, [1] second-pass overflow count, [2] spill slots used */
@@ -295,10 +296,10 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_PICK>), dim3((j1 - j0 + sa->pick_waves - 1) / sa->pick_waves), dim3(64 * sa->pick_waves),
 			                   4096u + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_pick, sa->d_todo, sa->d_counts,
-			                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec, j0, j1);
+			                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
 			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), 4096u + sa->per_wave_rest, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
-			                   sa->d_prof, sa->big, sa->d_pickrec, j0, j1);
+			                   sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
 		}
 		if (slices >= 2) {
 			HIPCHK(hipEventRecord(sa->ev_join, sa->stream2));
@@ -308,14 +309,14 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	if (!sa->split_nbr || sa->adaptive) { /* whichever form Control::nbr_single names does the work, the other returns at once */
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
-		                   sa->d_prof, sa->big, sa->d_pickrec, 0u, K);
+		                   sa->d_prof, sa->big, sa->d_pickrec, 0u, K, sa->d_pickstate);
 	}
 	/* the few whose change lists overflowed LDS (or that need a second top-K pick): the whole
 	 * evaluation in one kernel, lists in global scratch */
 	const uint32_t bigblocks = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* one per neighbour: none is dropped */
 	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   (unsigned long long*)nullptr, sa->big, sa->split_nbr ? sa->d_pickrec : (uint4*)nullptr, 0u, K);
+	                   (unsigned long long*)nullptr, sa->big, sa->split_nbr ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
 	/* and whatever overflowed even that: exact full walk from byte 0 */
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
@@ -358,7 +359,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->d_todo2); dfree(sa->d_counts); dfree(sa->d_pickrec);
+	dfree(sa->d_todo2); dfree(sa->d_counts); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->ab.span_pos); dfree(sa->ab.span_ev); dfree(sa->ab.jobs_b); dfree(sa->ab.jobs_c);
@@ -599,6 +600,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_REST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
+		HIPCHK(hipMalloc(&sa->d_pickstate, sizeof(uint4) * 2 * K));
 		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
 		if (!sa->split_nbr) { /* one-kernel form only */

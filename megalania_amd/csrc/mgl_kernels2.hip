@@ -541,7 +541,7 @@ template <bool BIG, int MODE>
 __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : (MODE == MGL_NBR_PICK ? 2 : 4))) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
-                                                     BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end)
+                                                     BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate)
 {
 	/* the step picks one of the two forms of the regular launch on the device (k_step_end): split
 	 * while repairs are rare (their second pass costs a lone wavefront's latency), one kernel
@@ -604,9 +604,16 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MG
 	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
 	NbrRng rng; rng.key = mgl_rng_key(seed, gstep, j); rng.n = 0;
 
-	/* target (same rule as the full-walk path) */
+	/* target (same rule as the full-walk path) and the walk state there; the second half of a split
+	 * launch takes both from the first half's record instead of drawing and searching again */
 	uint32_t target;
-	{
+	mgl_wstate nb; /* neighbour's walk state */
+	if (MODE == MGL_NBR_REST) {
+		const uint4 s0 = pickstate[2u * j], s1 = pickstate[2u * j + 1u];
+		target = s0.x; rng.n = s0.y;
+		nb.pos = target; nb.ctx_state = s0.z;
+		nb.dists[0] = s0.w; nb.dists[1] = s1.x; nb.dists[2] = s1.y; nb.dists[3] = s1.z;
+	} else {
 		uint32_t mydraw = lane < 32 ? mgl_rng_draw(rng.key, lane) % c.n : 0;
 		bool on = lane < 32 && ((b.onwalk[mydraw >> 6] >> (mydraw & 63u)) & 1ull);
 		unsigned long long m = __ballot(on);
@@ -622,13 +629,17 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MG
 			while (!bits && ++wd < b.nw0) bits = b.onwalk[wd];
 			target = uni(bits ? (wd << 6) + ctz64(bits) : 0u);
 		}
+		nb = uni_state(base_state_at(b, target));
+		if (MODE == MGL_NBR_PICK && lane == 0) {
+			pickstate[2u * j] = make_uint4(target, rng.n, nb.ctx_state, nb.dists[0]);
+			pickstate[2u * j + 1u] = make_uint4(nb.dists[1], nb.dists[2], nb.dists[3], 0u);
+		}
 	}
 	Prof prof;
 	prof_start(prof, prof_acc);
 	ch.dbg = prof_acc;
 	ch.diag = c.diag_stop;
 	const uint32_t pos = target;
-	mgl_wstate nb = uni_state(base_state_at(b, pos)); /* neighbour's walk state */
 	mgl_wstate bs = nb;                               /* base's walk state */
 	Win win; win.base = 0xFFFFFFFFu; win.pk = 0; win.byte = 0;
 	Walk tw; /* scratch Walk for top-K (its window is the input window at the query position) */

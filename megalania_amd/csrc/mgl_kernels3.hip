@@ -135,17 +135,23 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 			while (ji < nd && s_jpos[ji] < p) ji++;
 			const mgl_pk pk = (ji < nd && s_jpos[ji] == p) ? s_jnew[ji] : old_at_p;
 			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
-			mgl_plan npl;
-			plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
 			const bool paired = bs.pos == p;
+			/* identical coding cancels; decided before anything is planned (as in the neighbour kernel) */
 			bool cancelled = false;
-			mgl_plan bpl;
+			if (paired && old_at_p == pk && nb.ctx_state == bs.ctx_state) {
+				cancelled = true;
+				if (ntype == MGL_LITERAL && nb.ctx_state >= 7) {
+					const uint32_t mn = nb.dists[0] < p ? c.data[p - nb.dists[0] - 1] : 0u;
+					const uint32_t mb = bs.dists[0] < p ? c.data[p - bs.dists[0] - 1] : 0u;
+					cancelled = mn == mb;
+				}
+			}
+			mgl_plan npl, bpl;
 			uint32_t btype = 0, bdist = 0, blen = 0;
-			if (paired) {
-				btype = mgl_pk_type(old_at_p); bdist = mgl_pk_dist(old_at_p); blen = mgl_pk_len(old_at_p);
-				plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
-				cancelled = old_at_p == pk && nb.ctx_state == bs.ctx_state &&
-				            (ntype != MGL_LITERAL || nb.ctx_state < 7 || npl.match_byte == bpl.match_byte);
+			if (paired) { btype = mgl_pk_type(old_at_p); bdist = mgl_pk_dist(old_at_p); blen = mgl_pk_len(old_at_p); }
+			if (!cancelled) {
+				plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+				if (paired) plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
 			}
 			/* base structures at p: on the new walk; special iff not a literal */
 			if (lane == 0) {

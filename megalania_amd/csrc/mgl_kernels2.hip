@@ -482,6 +482,53 @@ __device__ __forceinline__ void plan_at(const DevCtx& c, const mgl_wstate& st, u
 	mgl_plan_packet(&c.L, &st, type, dist, len, byte, match_byte, prev_byte, &pl);
 }
 
+/* Base packets the neighbour's walk has passed over disappear, and under a freshly picked match
+ * they are mostly a run of plain literals (ctx_state < 7, so no match byte): up to seven of them
+ * are planned at once, nine lanes each (is_match + the eight literal bits), instead of one per
+ * turn of the walk loop.  Uses only the slab / input window in registers.  Returns the number of
+ * packets removed (0: not a plain-literal run of at least two -- take the packet-at-a-time path). */
+template <bool INS>
+__device__ __forceinline__ uint32_t literal_run_events(const DevCtx& c, Changes& ch, const Win& win, mgl_wstate& st, uint32_t limit, uint32_t lane)
+{
+	if (st.ctx_state >= 7u) return 0;
+	const uint32_t o = st.pos - win.base;
+	const unsigned long long lit = __ballot(mgl_pk_type(win.pk) == MGL_LITERAL) >> o; /* window entries from st.pos on */
+	uint32_t run = (uint32_t)__ffsll((long long)~lit) - 1u; /* consecutive literals: each one's successor is on the walk */
+	if (~lit == 0ull) run = 64u;
+	run = run < 64u - o ? run : 64u - o;
+	run = run < limit ? run : limit;
+	if (run < 2u) return 0;
+	const uint32_t take = run < 7u ? run : 7u;
+	uint32_t& n = INS ? ch.n_ins : ch.n_rem;
+	if (n + 9u * take > ch.cap) { ch.overflow = true; return take; }
+	const uint32_t i = lane / 9u, slot = lane - i * 9u;
+	const uint32_t p = st.pos + i;
+	const bool active = i < take;
+	const uint32_t byte = (uint32_t)__shfl((int)win.byte, (int)((p - win.base) & 63u), 64);
+	uint32_t prev_byte = 0;
+	if (c.L.lc > 0) {
+		const uint32_t wprev = (uint32_t)__shfl((int)win.byte, (int)((p - 1u - win.base) & 63u), 64);
+		prev_byte = p == 0 ? 0u : (p - 1u >= win.base ? wprev : (uint32_t)c.data[p - 1u]);
+	}
+	mgl_wstate sv = st;
+	sv.pos = p;
+	sv.ctx_state = lit_steps(st.ctx_state, i);
+	mgl_plan pl;
+	mgl_plan_packet(&c.L, &sv, MGL_LITERAL, 0, 1, byte, 0, prev_byte, &pl);
+	if (__ballot(active && pl.nev != 9u)) return 0; /* not the 1 + 8 events assumed above: one at a time */
+	if (active) {
+		uint32_t ctx, bit;
+		mgl_plan_event(&pl, slot, &ctx, &bit);
+		const uint32_t at = n + i * 9u + slot;
+		if (INS) { ch.ins_key[at] = (uint16_t)(ctx | (bit << 15)); ch.ins_pos[at] = p; }
+		else { ch.rem_key[at] = (uint16_t)ctx; ch.rem_pos[at] = p; }
+	}
+	n += 9u * take;
+	st.pos += take;
+	st.ctx_state = lit_steps(st.ctx_state, take);
+	return take;
+}
+
 /* The base's adaptive model before the first base packet at or after y, into LDS: dense
  * checkpoint + replay of < 2^MGL_CK2_SHIFT bytes of base packets. */
 __device__ void model_load(const DevCtx& c, const Base2& b, uint16_t* probs, const uint16_t* T, uint32_t y, uint32_t lane)
@@ -875,6 +922,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MG
 				} else {
 					/* ---- a base packet the neighbour has already passed over: its events go away */
 					win_cover(win, c, b.slab, bs.pos, lane);
+					if (literal_run_events<false>(c, ch, win, bs, (nb.pos < c.n ? nb.pos : c.n) - bs.pos, lane)) continue;
 					const mgl_pk bpk = win_pk(win, bs.pos);
 					mgl_plan bpl;
 					plan_at(c, bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk), win_byte(win, bs.pos), bpl);

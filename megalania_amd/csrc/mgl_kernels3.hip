@@ -191,6 +191,45 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 			/* an old packet that is not on the new walk any more */
 			const uint32_t q = bs.pos;
 			win_cover(win, c, b.slab, q, lane);
+			if (bs.ctx_state < 7u) {
+				/* a run of plain literals goes seven at a time, nine lanes each (as in the neighbour kernel) */
+				const uint32_t o = q - win.base;
+				const unsigned long long lit = __ballot(mgl_pk_type(win.pk) == MGL_LITERAL) >> o;
+				uint32_t run = ~lit == 0ull ? 64u : (uint32_t)__ffsll((long long)~lit) - 1u;
+				const uint32_t limit = (nb.pos < c.n ? nb.pos : c.n) - q;
+				run = run < 64u - o ? run : 64u - o;
+				run = run < limit ? run : limit;
+				if (run >= 2u) {
+					const uint32_t take = run < 7u ? run : 7u;
+					if (n_rem + 9u * take > MGL_APPLY_CAP) { failed = true; break; }
+					const uint32_t i = lane / 9u, slot = lane - i * 9u, p = q + i;
+					const bool active = i < take;
+					const uint32_t byte = (uint32_t)__shfl((int)win.byte, (int)((p - win.base) & 63u), 64);
+					uint32_t prev_byte = 0;
+					if (c.L.lc > 0) {
+						const uint32_t wprev = (uint32_t)__shfl((int)win.byte, (int)((p - 1u - win.base) & 63u), 64);
+						prev_byte = p == 0 ? 0u : (p - 1u >= win.base ? wprev : (uint32_t)c.data[p - 1u]);
+					}
+					mgl_wstate sv = bs;
+					sv.pos = p; sv.ctx_state = lit_steps(bs.ctx_state, i);
+					mgl_plan pl;
+					mgl_plan_packet(&c.L, &sv, MGL_LITERAL, 0, 1, byte, 0, prev_byte, &pl);
+					if (!__ballot(active && pl.nev != 9u)) {
+						if (active) {
+							uint32_t ctx, bit;
+							mgl_plan_event(&pl, slot, &ctx, &bit);
+							ab.rem_key[n_rem + i * 9u + slot] = (uint16_t)ctx;
+							ab.rem_pos[n_rem + i * 9u + slot] = p;
+							atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+						}
+						n_rem += 9u * take;
+						if (lane == 0) b.onwalk[q >> 6] &= ~(((take >= 64u ? ~0ull : ((1ull << take) - 1ull))) << (q & 63u)); /* literals are never special */
+						dpackets -= (int32_t)take;
+						bs.pos += take; bs.ctx_state = lit_steps(bs.ctx_state, take);
+						continue;
+					}
+				}
+			}
 			const mgl_pk bpk = win_pk(win, q);
 			const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
 			mgl_plan bpl;

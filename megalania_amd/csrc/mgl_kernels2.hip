@@ -548,6 +548,42 @@ __device__ void model_load(const DevCtx& c, const Base2& b, uint16_t* probs, con
 		w.st = uni_state(base_state_at(b, start));
 		while (w.st.pos < y) {
 			walk_window(w, c, b.slab, lane);
+			if (w.st.ctx_state < 7u) {
+				/* a run of plain literals: up to seven are planned at once, nine lanes each; their
+				 * probability updates are then applied packet by packet (the packets share contexts:
+				 * is_match and the top of the literal tree), which is all that has to stay in order */
+				const uint32_t o = w.st.pos - w.wbase;
+				const unsigned long long lit = __ballot(mgl_pk_type(w.wpk) == MGL_LITERAL) >> o;
+				uint32_t run = ~lit == 0ull ? 64u : (uint32_t)__ffsll((long long)~lit) - 1u;
+				run = run < 64u - o ? run : 64u - o;
+				run = run < y - w.st.pos ? run : y - w.st.pos;
+				if (run >= 2u) {
+					const uint32_t take = run < 7u ? run : 7u;
+					const uint32_t i = lane / 9u, slot = lane - i * 9u, p = w.st.pos + i;
+					const bool active = i < take;
+					const uint32_t byte = (uint32_t)__shfl((int)w.wbyte, (int)((p - w.wbase) & 63u), 64);
+					uint32_t prev_byte = 0;
+					if (c.L.lc > 0) {
+						const uint32_t wprev = (uint32_t)__shfl((int)w.wbyte, (int)((p - 1u - w.wbase) & 63u), 64);
+						prev_byte = p == 0 ? 0u : (p - 1u >= w.wbase ? wprev : (uint32_t)c.data[p - 1u]);
+					}
+					mgl_wstate sv = w.st;
+					sv.pos = p; sv.ctx_state = lit_steps(w.st.ctx_state, i);
+					mgl_plan pl;
+					mgl_plan_packet(&c.L, &sv, MGL_LITERAL, 0, 1, byte, 0, prev_byte, &pl);
+					if (!__ballot(active && pl.nev != 9u)) {
+						uint32_t ctx = 0, bit = 0;
+						if (active) mgl_plan_event(&pl, slot, &ctx, &bit);
+						for (uint32_t r = 0; r < take; r++) {
+							if (active && i == r) probs[ctx] = (uint16_t)mgl_prob_update(probs[ctx], bit);
+							wave_sync();
+						}
+						w.st.pos += take; w.st.ctx_state = lit_steps(w.st.ctx_state, take);
+						w.packets += take;
+						continue;
+					}
+				}
+			}
 			const mgl_pk pk = walk_slab_at(w, w.st.pos);
 			walk_packet<true>(w, c, probs, T, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), lane);
 		}

@@ -651,6 +651,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
                                                     uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                     const uint32_t* todo, const uint32_t* todo_count)
 {
+	if (todo && blockIdx.x * (blockDim.x >> 6) >= *todo_count) return; /* nothing listed for this workgroup: before any load */
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];

@@ -629,11 +629,14 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MG
 	/* the step picks one of the two forms of the regular launch on the device (k_step_end): split
 	 * while repairs are rare (their second pass costs a lone wavefront's latency), one kernel
 	 * otherwise; the form not picked returns before touching anything */
-	const uint32_t form_single = BIG ? 0u : ctl->nbr_single; /* in flight together with the table loads below */
+	/* decided before anything else is loaded: a launch with nothing to do (the form not chosen, a
+	 * second pass with an empty list) costs its dispatch and one load per workgroup */
+	if (BIG) {
+		if (blockIdx.x * (blockDim.x >> 6) >= *big.todo_in_count) return;
+	} else if ((MODE == MGL_NBR_FULL) != (ctl->nbr_single != 0)) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
-	if (!BIG && ((MODE == MGL_NBR_FULL) != (form_single != 0))) return;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint32_t j = j_base + blockIdx.x * (blockDim.x >> 6) + wid; /* [j_base, j_end): the slice of the step this launch covers */

@@ -264,8 +264,7 @@ static int launch_apply(mgl_sa* sa)
 	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
-	hipLaunchKernelGGL(k_build, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, 2);
-	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->snapshots ? 1 : 0, sa->d_counts, sa->adaptive ? 1 : 0);
+	hipLaunchKernelGGL(k_build_end, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->snapshots ? 1 : 0, sa->d_counts, sa->adaptive ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -614,6 +613,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		sa->pick_waves = getenv("MGL_PICK_WAVES") ? (uint32_t)atoi(getenv("MGL_PICK_WAVES")) : (n <= (1u << 20) ? 2u : 1u);
 		if (sa->pick_waves < 1 || sa->pick_waves > 2) sa->pick_waves = 1;
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_build_end, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
 
 	sa->sqrt_thresh = ceil_sqrt_u64(sa->cfg.iters_per_epoch);

@@ -31,7 +31,7 @@ __device__ __forceinline__ void bitacc_move(BitAcc& a, uint64_t* arr, uint32_t n
 	a.word = new_word; a.bits = 0;
 }
 
-__global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, int check_cost)
+__device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int check_cost)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
@@ -210,6 +210,21 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 			ctl->full_rebuilds++;
 		}
 	}
+}
+
+__global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, int check_cost)
+{
+	build_body(c, b, ctl, check_cost);
+}
+/* the tail of an incremental step in one launch: the fallback rebuild (only when k_apply_* gave
+ * up) and then the step's bookkeeping (mgl_kernels3.hip) */
+__device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int adaptive);
+__global__ void __launch_bounds__(64) k_build_end(DevCtx c, Base2 b, Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
+{
+	build_body(c, b, ctl, 2);
+	__threadfence();
+	wave_sync();
+	step_end_body(ctl, lazy_best, counts, adaptive);
 }
 
 /* ================================================================== change lists */

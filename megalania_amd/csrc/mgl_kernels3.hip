@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 }
 
 /* decide-only variant of the step's tail: flags for k_build's conditional run are reset there */
-__global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
+__device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
 		if (adaptive) {
@@ -680,6 +680,10 @@ __global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int ad
 		/* the per-step counters: kept for diagnostics in [4..7], cleared for the next step (saves a memset launch) */
 		for (int i = 0; i < 4; i++) { counts[4 + i] = counts[i]; counts[i] = 0; }
 	}
+}
+__global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
+{
+	step_end_body(ctl, lazy_best, counts, adaptive);
 }
 
 /* ================================================================== base snapshots

@@ -760,7 +760,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		if ((rc = launch_neighbours(sa, ~0ull, s == 0 || !(sa->incremental && sa->incremental_apply)))) return rc;
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
 		const bool inc_apply = sa->incremental && sa->incremental_apply;
-		hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
+		hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
 		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh, inc_apply ? 0 : 1);
 		HIPCHK(hipGetLastError());
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));

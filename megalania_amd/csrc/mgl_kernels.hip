@@ -816,31 +816,38 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 /* ================================================================== k_decide */
 /* Best-of-K + the accept rule of main.c:86-96, then the winner's
  * journal is applied to the base slab.  One block. */
-__global__ void __launch_bounds__(256) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, uint32_t K, uint64_t seed,
-                                                uint64_t iters_per_epoch, uint64_t sqrt_thresh, int apply_journal)
+__global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, uint32_t K, uint64_t seed,
+                                                 uint64_t iters_per_epoch, uint64_t sqrt_thresh, int apply_journal)
 {
-	__shared__ uint64_t s_key[256];
-	__shared__ uint64_t s_cnt[256 * 2];
+	__shared__ uint64_t s_key[16];
+	__shared__ uint64_t s_cnt[16 * 2];
 	__shared__ uint32_t s_winner;
 	const uint32_t tid = threadIdx.x;
 	uint64_t best = MGL_INVALID_COST, valid = 0, walked = 0;
-	for (uint32_t j = tid; j < K; j += 256) {
+	for (uint32_t j = tid; j < K; j += blockDim.x) {
 		const uint64_t cst = out.cost[j];
+		const uint64_t wk = out.walked[j]; /* both loads in flight together */
 		if (cst != MGL_INVALID_COST) {
-			valid++; walked += out.walked[j];
+			valid++; walked += wk;
 			const uint64_t key = (cst << 20) | j;
 			best = key < best ? key : best;
 		}
 	}
-	s_key[tid] = best; s_cnt[tid] = valid; s_cnt[256 + tid] = walked;
+	/* per wavefront through lane exchanges, then one value per wavefront through LDS */
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint64_t ob = (uint64_t)__shfl_xor((unsigned long long)best, o, 64);
+		best = ob < best ? ob : best;
+		valid += (uint64_t)__shfl_xor((unsigned long long)valid, o, 64);
+		walked += (uint64_t)__shfl_xor((unsigned long long)walked, o, 64);
+	}
+	if ((tid & 63u) == 0) { s_key[tid >> 6] = best; s_cnt[tid >> 6] = valid; s_cnt[16 + (tid >> 6)] = walked; }
 	__syncthreads();
-	for (uint32_t o = 128; o > 0; o >>= 1) {
-		if (tid < o) {
-			s_key[tid] = s_key[tid + o] < s_key[tid] ? s_key[tid + o] : s_key[tid];
-			s_cnt[tid] += s_cnt[tid + o];
-			s_cnt[256 + tid] += s_cnt[256 + tid + o];
+	if (tid == 0) {
+		for (uint32_t w = 1; w < (blockDim.x >> 6); w++) {
+			s_key[0] = s_key[w] < s_key[0] ? s_key[w] : s_key[0];
+			s_cnt[0] += s_cnt[w];
+			s_cnt[16] += s_cnt[16 + w];
 		}
-		__syncthreads();
 	}
 	if (tid == 0) {
 		const uint64_t gstep = ctl->gstep, i = ctl->iter;
@@ -859,7 +866,7 @@ __global__ void __launch_bounds__(256) k_decide(DevCtx c, BaseView b, Control* c
 		}
 		ctl->evals += s_cnt[0];
 		ctl->failed += K - s_cnt[0];
-		ctl->packets_eval += s_cnt[256];
+		ctl->packets_eval += s_cnt[16];
 		ctl->gstep = gstep + 1;
 		ctl->iter = i + 1;
 		ctl->winner = winner;

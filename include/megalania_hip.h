@@ -123,6 +123,21 @@ void mgl_sa_destroy(mgl_sa* sa);
 int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best);
 /* Replace the current slab (n entries, position-indexed).  Must be a valid parse. */
 int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets);
+/* Replace the current slab by a greedy LZ parse made on the device (not in the reference, whose
+ * search always starts from the all-literal slab, main.c:71; SURVEY 8f-3 "greedy seeding"): every
+ * position independently receives the longest match among the `candidates` nearest earlier
+ * occurrences of its two and of its four leading bytes inside the dictionary window (nearest
+ * among equals; len 2 only up to distance 128, len 3 up to 2^14), or a literal; the slab walk
+ * picks the parse out of them.  Same effect on the handle as mgl_sa_set_slab. */
+int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates);
+/* Opt-in Metropolis accept rule (not in the reference, whose rule ignores the cost difference,
+ * main.c:86).  temperature = 0 (default): the reference's rule.  temperature > 0, in
+ * cost units (16384 per output byte, main.c:97): when the step's best neighbour does not improve,
+ * the randomly drawn neighbour is accepted iff u < exp(-delta / t_eff) with u uniform, evaluated in
+ * integers through the reference's log table (perplexity_table.h:4): delta * 2048 <=
+ * t_eff * T[u], u in 1..2047, t_eff = temperature * (iters_per_epoch - i) / iters_per_epoch
+ * (linear cooling inside the epoch).  Must be below 2^40. */
+int mgl_sa_set_temperature(mgl_sa* sa, uint64_t temperature);
 /* Adopt a best slab found elsewhere (another chain / GPU): replaces best slab and best cost.
  * `perplexity` must be the slab's exact cost (it is re-derived on the device and checked). */
 int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t perplexity);

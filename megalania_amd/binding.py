@@ -30,7 +30,7 @@ F_SERIAL_BUILD = 16
 
 HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
-    "mgl_sa_set_slab", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
+    "mgl_sa_set_slab", "mgl_sa_seed_greedy", "mgl_sa_set_temperature", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
     "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump", "mgl_debug_set",
 ]
 HOST_SYMBOLS = [
@@ -93,6 +93,8 @@ def hip_lib():
         L.mgl_sa_destroy.argtypes = [C.c_void_p]
         L.mgl_sa_begin_epoch.argtypes = [C.c_void_p, C.c_uint, C.c_int]
         L.mgl_sa_set_slab.argtypes = [C.c_void_p, C.c_void_p]
+        L.mgl_sa_seed_greedy.argtypes = [C.c_void_p, C.c_uint32]
+        L.mgl_sa_set_temperature.argtypes = [C.c_void_p, C.c_uint64]
         L.mgl_sa_set_best.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mgl_sa_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats)]
         L.mgl_sa_current.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
@@ -189,6 +191,14 @@ class SA:
     def set_slab(self, slab):
         slab = np.ascontiguousarray(slab, dtype=PACKET)
         self._chk(self.L.mgl_sa_set_slab(self.h, _ptr(slab)))
+
+    def seed_greedy(self, candidates: int = 256):
+        """Current slab := greedy LZ parse made on the device (opt-in starting point)."""
+        self._chk(self.L.mgl_sa_seed_greedy(self.h, candidates))
+
+    def set_temperature(self, temperature: int):
+        """Opt-in Metropolis accept rule, temperature in cost units (16384 per byte); 0 = reference rule."""
+        self._chk(self.L.mgl_sa_set_temperature(self.h, temperature))
 
     def set_best(self, slab, perplexity: int):
         slab = np.ascontiguousarray(slab, dtype=PACKET)

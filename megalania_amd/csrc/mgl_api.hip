@@ -60,6 +60,7 @@ struct mgl_sa {
 	uint32_t n;
 	mgl_properties props;
 	mgl_sa_config cfg;
+	uint64_t temperature = 0; /* mgl_sa_set_temperature: 0 = the reference's accept rule */
 	DevCtx ctx;
 	uint8_t* d_data;
 	uint32_t* d_bucket_off;
@@ -733,6 +734,33 @@ extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
 	return MGL_OK;
 }
 
+extern "C" int mgl_sa_set_temperature(mgl_sa* sa, uint64_t temperature)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	if (temperature >> 40) return fail(MGL_EINVAL, "mgl_sa_set_temperature: temperature must be below 2^40 cost units");
+	sa->temperature = temperature;
+	return MGL_OK;
+}
+
+extern "C" int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	if (candidates == 0) return fail(MGL_EINVAL, "mgl_sa_seed_greedy: candidates must be > 0");
+	HIPCHK(hipSetDevice(sa->device));
+	Control c;
+	int rc = read_ctl(sa, sa->base, &c);
+	if (rc) return rc;
+	if ((rc = keep_best_before_overwrite(sa, c))) return rc;
+	hipLaunchKernelGGL(k_greedy_seed, dim3((sa->ctx.n + 255u) / 256u), dim3(256), 0, sa->stream, sa->ctx, sa->base.v.slab, candidates);
+	HIPCHK(hipGetLastError());
+	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
+	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
+	if ((rc = rebuild_base(sa, 0))) return rc;
+	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
+	if (c.error_flags) return fail(MGL_EDEVICE, "mgl_sa_seed_greedy: the seeded slab failed the walk check");
+	return MGL_OK;
+}
+
 static hipEvent_t pool_event(mgl_sa* sa, size_t i)
 {
 	while (sa->ev_pool.size() <= i) {
@@ -761,7 +789,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
 		const bool inc_apply = sa->incremental && sa->incremental_apply;
 		hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
-		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh, inc_apply ? 0 : 1);
+		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh, inc_apply ? 0 : 1, sa->temperature);
 		HIPCHK(hipGetLastError());
 		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
 		if (inc_apply) {

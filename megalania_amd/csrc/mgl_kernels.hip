@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 /* Best-of-K + the accept rule of main.c:86-96, then the winner's
  * journal is applied to the base slab.  One block. */
 __global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, uint32_t K, uint64_t seed,
-                                                 uint64_t iters_per_epoch, uint64_t sqrt_thresh, int apply_journal)
+                                                 uint64_t iters_per_epoch, uint64_t sqrt_thresh, int apply_journal, uint64_t temperature)
 {
 	__shared__ uint64_t s_key[16];
 	__shared__ uint64_t s_cnt[16 * 2];
@@ -859,7 +859,19 @@ __global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* 
 			const uint64_t m = i * i + 1 + (uint64_t)ctl->phase * iters_per_epoch / 2;
 			const bool transition = ((uint64_t)mgl_rng_draw(key, 0) % m) < sqrt_thresh;
 			if (ctl->cur_cost == 0 || bcost < ctl->cur_cost) winner = (uint32_t)(bkey & 0xFFFFFu);
-			else if (transition) {
+			else if (temperature) {
+				/* opt-in Metropolis rule (not in the reference; mgl_sa_set_temperature): the random
+				 * neighbour is taken iff u < exp(-delta / t), through the cost table: T[u] = -log2(u / 2048) * 2048 */
+				const uint32_t jr = mgl_rng_draw(key, 1) % K;
+				const uint64_t cj = out.cost[jr];
+				if (cj != MGL_INVALID_COST) {
+					const uint32_t u = mgl_rng_draw(key, 0) % 2047u + 1u;
+					const uint64_t ic = i < iters_per_epoch ? i : iters_per_epoch;
+					const uint64_t t_eff = temperature * (iters_per_epoch - ic) / iters_per_epoch;
+					const uint64_t delta = cj - ctl->cur_cost;
+					if (delta * 2048u <= t_eff * (uint64_t)c.cost_tbl[u]) winner = jr;
+				}
+			} else if (transition) {
 				const uint32_t jr = mgl_rng_draw(key, 1) % K;
 				if (out.cost[jr] != MGL_INVALID_COST) winner = jr;
 			}

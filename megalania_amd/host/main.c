@@ -27,10 +27,14 @@ static void usage(const char* argv0)
 	fprintf(stderr,
 	        "usage: %s [--neighbours K] [--epochs E] [--phases P] [--steps S] [--seed N]\n"
 	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M]\n"
-	        "          [-o out.lzma] [--save-slab file] [--load-slab file] filename\n"
+	        "          [-o out.lzma] [--save-slab file] [--load-slab file] [--greedy-seed C] [--temperature B] filename\n"
 	        "  -o           write the stream to a file instead of stdout\n"
 	        "  --save-slab  after every epoch, write the best packet slab (resumable checkpoint)\n"
-	        "  --load-slab  start from a slab written by --save-slab (same input, same lc/lp/pb)\n", argv0);
+	        "  --load-slab  start from a slab written by --save-slab (same input, same lc/lp/pb)\n"
+	        "  --greedy-seed C  epochs that the reference starts from the all-literal slab start from a greedy\n"
+	        "               parse instead (longest of the C nearest candidates per position; e.g. 256)\n"
+	        "  --temperature B  Metropolis accept rule instead of the reference's: B = e-folding slack in output\n"
+	        "               bytes at the start of an epoch, cooled linearly to 0 (e.g. 2; 0 = reference rule)\n", argv0);
 }
 
 int main(int argc, char** argv)
@@ -45,6 +49,8 @@ int main(int argc, char** argv)
 	unsigned long long steps_override = 0;
 	const char* filename = NULL;
 	const char *out_path = NULL, *save_path = NULL, *load_path = NULL;
+	uint32_t greedy = 0;
+	double temperature_bytes = 0;
 	for (int i = 1; i < argc; i++) {
 		const char* a = argv[i];
 		const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -63,6 +69,8 @@ int main(int argc, char** argv)
 		else if (!strcmp(a, "-o")) out_path = v;
 		else if (!strcmp(a, "--save-slab")) save_path = v;
 		else if (!strcmp(a, "--load-slab")) load_path = v;
+		else if (!strcmp(a, "--greedy-seed")) greedy = (uint32_t)strtoul(v, NULL, 0);
+		else if (!strcmp(a, "--temperature")) temperature_bytes = strtod(v, NULL);
 		else { usage(argv[0]); return -1; }
 		i++;
 	}
@@ -85,6 +93,10 @@ int main(int argc, char** argv)
 	mgl_sa* sa = mgl_sa_create(file_data, file_size, props, &cfg);
 	if (sa == NULL) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 
+	if (temperature_bytes > 0 && mgl_sa_set_temperature(sa, (uint64_t)(temperature_bytes * 16384.0)) != MGL_OK) {
+		fprintf(stderr, "Error: %s\n", mgl_last_error());
+		return -1;
+	}
 	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
 	if (packets_best == NULL) { fprintf(stderr, "Error: out of memory\n"); return -1; }
 	bool resumed = false;
@@ -109,6 +121,7 @@ int main(int argc, char** argv)
 	for (unsigned phase = 0; phase < phases; phase++) {
 		for (unsigned epoch = 0; epoch < epochs; epoch++) {
 			if (mgl_sa_begin_epoch(sa, phase, phase != 0 || resumed) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+			if (greedy && phase == 0 && !resumed && mgl_sa_seed_greedy(sa, greedy) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 			mgl_sa_stats st;
 			if (mgl_sa_run(sa, steps_per_epoch, &st) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 			/* main.c:97-99: 18 = 13 header bytes + 5 flush bytes, 16384 = 2048 * 8 */

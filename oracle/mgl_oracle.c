@@ -74,7 +74,10 @@ struct orc_ctx {
 	/* match index, ref: substring_enumerator.c:9-47 */
 	uint32_t* bucket_off; /* 65536+1 */
 	uint32_t* bucket_pos; /* n-1 positions, ascending inside a bucket */
+	uint64_t temperature; /* 0 = the reference's accept rule; else the opt-in Metropolis rule of orc_sa_batched */
 };
+
+void orc_set_temperature(orc_ctx* c, uint64_t temperature) { c->temperature = temperature; }
 
 size_t orc_num_probs(const orc_ctx* c) { return c->L.total; }
 
@@ -894,7 +897,11 @@ static uint64_t ceil_sqrt_u64(uint64_t x)
 
 /* one step = K neighbours of the same base slab, then one decision.
  * The decision keeps the shape of main.c:86-96: take the best neighbour if it improves,
- * otherwise (with the reference's i-dependent probability) take a random one. */
+ * otherwise (with the reference's i-dependent probability) take a random one.
+ * Opt-in, not in the reference (its rule ignores the cost difference): with a
+ * temperature t > 0 the random neighbour jr is taken iff u < exp(-delta / t'), u uniform, written
+ * with the reference's own log table: delta * 2048 <= t_eff * T[u], u in 1..2047, t_eff = t cooled
+ * linearly to 0 over the epoch.  Integer arithmetic throughout. */
 int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_io,
                    uint64_t* best_cost_io, uint64_t seed, uint32_t K, unsigned phase,
                    uint64_t iters_per_epoch, uint64_t step_begin, uint64_t step_end,
@@ -917,7 +924,16 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 		uint32_t winner = ~0u;
 		if (bestj != ~0u) {
 			if (cur == 0 || bestc < cur) winner = bestj;
-			else if (transition) {
+			else if (c->temperature) {
+				uint32_t jr = orc_draw(seed, s, 0xFFFFFFFFu, 1) % K;
+				if (costs[jr] != ~0ull) {
+					const uint32_t u = orc_draw(seed, s, 0xFFFFFFFFu, 0) % 2047u + 1u;
+					const uint64_t ic = i < iters_per_epoch ? i : iters_per_epoch;
+					const uint64_t t_eff = c->temperature * (iters_per_epoch - ic) / iters_per_epoch;
+					const uint64_t delta = costs[jr] - cur; /* the best neighbour did not improve: >= 0 */
+					if (delta * 2048u <= t_eff * (uint64_t)orc_cost_table()[u]) winner = jr;
+				}
+			} else if (transition) {
 				uint32_t jr = orc_draw(seed, s, 0xFFFFFFFFu, 1) % K;
 				if (costs[jr] != ~0ull) winner = jr;
 			}

@@ -88,6 +88,9 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab_io, orc_packet* best_io, uint64_
                    uint64_t iters_per_epoch, uint64_t step_begin, uint64_t step_end,
                    uint64_t* trace, uint64_t* valid_evals);
 
+/* Opt-in Metropolis rule for orc_sa_batched (0 = the reference's rule); mirrors mgl_sa_set_temperature. */
+void orc_set_temperature(orc_ctx* c, uint64_t temperature);
+
 /* Emission (header + range coder), lzma_header_encoder.c:5-21 + range_encoder.c:18-101. */
 size_t orc_emit(orc_ctx* c, const orc_packet* slab, uint8_t* out, size_t cap);
 

@@ -104,6 +104,7 @@ class Oracle:
             L.orc_sa_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.c_uint32, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                          C.c_void_p]
+            L.orc_set_temperature.argtypes = [C.c_void_p, C.c_uint64]
             L.orc_emit.restype = C.c_size_t
             L.orc_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
             cls._lib = L
@@ -187,6 +188,9 @@ class Oracle:
                                   C.addressof(nd), cap)
         assert nd.value <= cap
         return bool(ok), cost.value, diffs[: nd.value].copy()
+
+    def set_temperature(self, temperature: int):
+        self.L.orc_set_temperature(self.h, temperature)
 
     def sa_batched(self, slab, best, cur, best_cost, seed, K, phase, iters_per_epoch, step_begin, step_end):
         trace = np.zeros(4 * max(1, step_end - step_begin), dtype=np.uint64)

@@ -4,6 +4,7 @@ best slab through the C host emitter, verify the stream with liblzma (and xz if 
 the reference CPU path (oracle/_ref, else the oracle) for the same number of *iterations*.
 
   python tools/end_to_end.py c2 100000 [cpu_iters]
+  MGL_GREEDY=256 python tools/end_to_end.py c2 20000 0    # start from the greedy seed (mgl_sa_seed_greedy)
 """
 import json, lzma, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,9 +22,15 @@ K = {"c1": 1024, "c2": 4096, "c3": 16384, "c5": 4096}[cfg]
 out = dict(config=cfg, input=desc, n=n, neighbours_per_step=K, steps=steps)
 sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=max(n, steps), **({"pb": 2} if cfg == "c5" else {}))
 t0 = time.perf_counter()
+greedy = int(os.environ.get("MGL_GREEDY", "0"))
+if greedy:
+    sa.seed_greedy(greedy)
+    _, seed_cost = sa.current()
+    out.update(greedy_candidates=greedy, greedy_seed_est_bytes=round(18 + seed_cost / 16384, 1), greedy_seed_seconds=round(time.perf_counter() - t0, 4))
+    print(f"greedy seed: est {18 + seed_cost / 16384:.1f} B in {time.perf_counter() - t0:.4f} s", flush=True)
 done, trace = 0, []
 while done < steps:
-    chunk = min(10000, steps - done)
+    chunk = min(10000 if steps > 20000 else 1000, steps - done)
     st = sa.run(chunk)
     done += chunk
     trace.append((done, st["best_cost"], round(time.perf_counter() - t0, 2)))

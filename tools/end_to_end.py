@@ -20,7 +20,12 @@ data, desc = corpus.config_input(cfg)
 n = len(data)
 K = {"c1": 1024, "c2": 4096, "c3": 16384, "c5": 4096}[cfg]
 out = dict(config=cfg, input=desc, n=n, neighbours_per_step=K, steps=steps)
-sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=max(n, steps), **({"pb": 2} if cfg == "c5" else {}))
+temp_bytes = float(os.environ.get("MGL_TEMP_BYTES", "0"))
+ipe = int(os.environ.get("MGL_IPE", "0")) or max(n, steps)
+sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=ipe, **({"pb": 2} if cfg == "c5" else {}))
+if temp_bytes:
+    sa.set_temperature(int(temp_bytes * 16384))
+    out.update(temperature_bytes=temp_bytes, iters_per_epoch=ipe)
 t0 = time.perf_counter()
 greedy = int(os.environ.get("MGL_GREEDY", "0"))
 if greedy:

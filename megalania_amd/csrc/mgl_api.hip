@@ -609,10 +609,25 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			c0.nbr_single = 1;
 			HIPCHK(hipMemcpy(sa->base.ctl, &c0, sizeof c0, hipMemcpyHostToDevice));
 		}
-		/* two pick wavefronts share a cost table per workgroup on small inputs (14 instead of 12 per CU);
-		 * on large ones top-K run times vary too much for wavefronts to wait on each other's LDS */
-		sa->pick_waves = getenv("MGL_PICK_WAVES") ? (uint32_t)atoi(getenv("MGL_PICK_WAVES")) : (n <= (1u << 20) ? 2u : 1u);
-		if (sa->pick_waves < 1 || sa->pick_waves > 2) sa->pick_waves = 1;
+		/* eight pick wavefronts share a cost table per workgroup: 4 KiB + 8 x 9.3 KiB = 78 KiB, two
+		 * workgroups = 16 wavefronts per CU, so the 4 096 neighbours of a c2 step are all resident at
+		 * once (with two per workgroup 14 fit and the last 512 waited for a slot: 127 -> 108 us).
+		 * Above 1 MiB top-K run times vary too much for wavefronts to hold each other's LDS: one per
+		 * workgroup there (c3, first 200 steps: 3.04 ms per step against 3.26 with eight) */
+		sa->pick_waves = getenv("MGL_PICK_WAVES") ? (uint32_t)atoi(getenv("MGL_PICK_WAVES")) : 0u;
+		if (sa->pick_waves != 1 && sa->pick_waves != 2 && sa->pick_waves != 4 && sa->pick_waves != 8) sa->pick_waves = 0;
+		{
+			/* the workgroup size that puts most wavefronts on a CU's 160 KiB (larger models -- lc > 0 -- fit fewer) */
+			uint32_t best_w = 1, best_resident = 0;
+			for (uint32_t w = 1; w <= 8; w *= 2) {
+				const uint32_t bytes = 4096u + w * sa->per_wave_pick;
+				if (bytes > 160u * 1024u) break;
+				const uint32_t resident = (160u * 1024u / ((bytes + 1279u) / 1280u * 1280u)) * w;
+				if (resident > best_resident) { best_resident = resident; best_w = w; }
+			}
+			if (n > (1u << 20)) best_w = 1;
+			if (sa->pick_waves == 0 || 4096u + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = best_w;
+		}
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build_end, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}

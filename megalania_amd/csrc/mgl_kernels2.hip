@@ -636,7 +636,7 @@ struct BigScratch {
 #define MGL_NBR_PICK 1
 #define MGL_NBR_REST 2
 template <bool BIG, int MODE>
-__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 128 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : (MODE == MGL_NBR_PICK ? 2 : 4))) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
+__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
                                                      BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate)

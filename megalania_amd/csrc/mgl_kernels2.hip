@@ -367,20 +367,22 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 		if (ch.diag == 42) { delta += p; continue; }
 		uint32_t iters = 0;
 		/* ---- part 1: while this context still has changes ahead (or a limit applies):
-		 * merge base entries and inserted events by position */
+		 * merge base entries and inserted events by position; the position of the next change of
+		 * either list is kept in a register */
+		uint32_t ipos = ipos0, rpos = rpos0;
 		for (;;) {
-			const bool pending = ii < ch.n_ins || ri < ch.n_rem;
+			const bool pending = ipos != MGL_POS_INF || rpos != MGL_POS_INF;
 			if (!pending && limit == MGL_POS_INF) break; /* -> part 2 */
 			iters++;
 			chunk(k);
 			const uint32_t bpos = pos_at(k);
-			const uint32_t ipos = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
 			if (ipos < bpos) {
 				if (ipos >= limit) { at_limit = true; ended = true; break; }
 				const uint32_t bit = ch.ins_key[ii] >> 15;
 				delta += T[bit ? 2048u - p : p];
 				p = mgl_prob_update(p, bit);
 				ii = next_with_ctx(ch.ins_key, ii + 1, ch.n_ins, cx, 0x7FFFu);
+				ipos = ii < ch.n_ins ? ch.ins_pos[ii] : MGL_POS_INF;
 				continue;
 			}
 			if (bpos == MGL_POS_INF) { ended = true; break; }          /* chain exhausted */
@@ -391,7 +393,6 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 				if (!pending) { ended = true; break; }   /* re-coupled, nothing ahead (limit mode) */
 				/* re-coupled, but this context changes again further on: everything up to
 				 * that position is coded exactly as in the base, so jump there */
-				const uint32_t rpos = ri < ch.n_rem ? ch.rem_pos[ri] : MGL_POS_INF;
 				const uint32_t nxt = ipos < rpos ? ipos : rpos;
 				if (nxt > bpos) {
 					if (nxt >= limit) { ended = true; break; } /* the base value holds at the limit */
@@ -402,8 +403,9 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 				}
 			}
 			delta -= T[bb ? 2048u - bp : bp];
-			if (ri < ch.n_rem && ch.rem_pos[ri] == bpos) {
+			if (rpos == bpos) {
 				ri = next_with_ctx(ch.rem_key, ri + 1, ch.n_rem, cx, 0xFFFFu);
+				rpos = ri < ch.n_rem ? ch.rem_pos[ri] : MGL_POS_INF;
 			} else {
 				delta += T[bb ? 2048u - p : p];
 				p = mgl_prob_update(p, bb);
@@ -418,6 +420,7 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 			uint32_t kb = k & ~15u;
 			uint4 a0 = *reinterpret_cast<const uint4*>(cev + kb);
 			uint4 a1 = *reinterpret_cast<const uint4*>(cev + kb + 8);
+			int32_t d32 = 0; /* 16 events x 22 528 at most per round: widened once per round */
 			while (!ended) {
 				/* may read up to 64 bytes past the sentinel: the pool is over-allocated for that */
 				const uint4 n0 = *reinterpret_cast<const uint4*>(cev + kb + 16);
@@ -433,10 +436,10 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 					const uint32_t ev = (wd >> ((h & 1u) * 16u)) & 0xFFFFu;
 					const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
 					if (p == bp) { ended = true; continue; }                   /* re-coupled */
-					delta += (int64_t)T[bb ? 2048u - p : p] - (int64_t)T[bb ? 2048u - bp : bp];
+					d32 += (int32_t)T[bb ? 2048u - p : p] - (int32_t)T[bb ? 2048u - bp : bp];
 					p = mgl_prob_update(p, bb);
-					iters++;
 				}
+				delta += d32; d32 = 0;
 				a0 = n0; a1 = n1; kb += 16;
 			}
 			k = kb;

@@ -121,13 +121,22 @@ def main():
         import torch
         import torch.distributed as dist
 
+        # rehearsal on a one-GPU box: MGL_BENCH_BACKEND=gloo MGL_BENCH_SHARE_GPU=1 runs the same code
+        # path with every rank on GPU 0 and the exchange over gloo (RCCL refuses two ranks per device)
+        backend = os.environ.get("MGL_BENCH_BACKEND", "nccl")
+        if os.environ.get("MGL_BENCH_SHARE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     n_gpus = world if world > 1 else 1
 
     from megalania_amd import binding, build as _build, corpus, multi_gpu
 
-    if local_rank == 0 and not os.environ.get("MGL_NO_AUTOBUILD"):
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0 and not os.environ.get("MGL_NO_AUTOBUILD"):
         _build.build_all()  # in-tree native build, no-op when current (there is no CPU search path to fall back to)
     if dist is not None:
         dist.barrier()
@@ -153,14 +162,14 @@ def main():
     st = sa.run(args.steps)
     if dist is not None:
         import torch
-        multi_gpu.exchange_best(sa, dist, device=torch.device("cuda", local_rank))
+        multi_gpu.exchange_best(sa, dist, device=coll_device)
     sync()
     elapsed = time.perf_counter() - t0
 
     evals, walked = st["evaluations"], st["packets_evaluated"]
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed, float(evals), float(walked)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, float(evals), float(walked)], dtype=torch.float64, device=coll_device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -127,8 +127,8 @@ int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets);
  * search always starts from the all-literal slab, main.c:71; SURVEY 8f-3 "greedy seeding"): every
  * position independently receives the longest match among the `candidates` nearest earlier
  * occurrences of its two and of its four leading bytes inside the dictionary window (nearest
- * among equals; len 2 only up to distance 128, len 3 up to 2^14), or a literal; the slab walk
- * picks the parse out of them.  Same effect on the handle as mgl_sa_set_slab. */
+ * among equals; len 2 only up to distance 128, len 3 up to 2^14; dropped when the next position
+ * would take a longer one), or a literal; the slab walk picks the parse out of them.  Same effect on the handle as mgl_sa_set_slab. */
 int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates);
 /* Opt-in Metropolis accept rule (not in the reference, whose rule ignores the cost difference,
  * main.c:86).  temperature = 0 (default): the reference's rule.  temperature > 0, in

@@ -139,7 +139,9 @@ __global__ void __launch_bounds__(256) ix_next2(const uint8_t* data, const uint3
  * nearest earlier positions with the same two bytes and the `cand` nearest earlier positions with
  * the same four bytes, inside the dictionary window; the longest match wins, the nearest among
  * equally long ones; it is kept if len >= 4, or len == 3 and distance <= 2^14, or len == 2 and
- * distance <= 128; otherwise the position holds a literal. */
+ * distance <= 128; and dropped again if the next position would take a longer match (the lazy
+ * step of LZ77 coders, decided per position from the same rule); otherwise the position holds a
+ * literal. */
 __device__ __forceinline__ uint32_t gs_lower_u32(const uint32_t* a, uint32_t lo, uint32_t hi, uint32_t x)
 {
 	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < x) lo = mid + 1; else hi = mid; }
@@ -150,44 +152,54 @@ __device__ __forceinline__ uint32_t gs_lower_u16(const uint16_t* a, uint32_t lo,
 	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < x) lo = mid + 1; else hi = mid; }
 	return lo;
 }
+/* longest match at p among the candidates (0 if none); *q_out = its source position */
+__device__ __forceinline__ uint32_t gs_best(const DevCtx& c, uint32_t p, uint32_t cand, uint32_t* q_out)
+{
+	const uint8_t* d = c.data;
+	const uint32_t maxlen = (c.n - p) < MGL_MAX_MATCH ? (c.n - p) : MGL_MAX_MATCH;
+	const uint32_t bigram = ((uint32_t)d[p] << 8) | d[p + 1];
+	const uint32_t b_lo = c.bucket_off[bigram], b_end = c.bucket_off[bigram + 1];
+	uint32_t best_len = 0, best_q = 0;
+	for (int src = 0; src < 2; src++) {
+		const uint32_t* pos_arr;
+		uint32_t lo, hi, from;
+		if (src == 0) {
+			pos_arr = c.bucket_pos; lo = b_lo;
+			hi = gs_lower_u32(pos_arr, b_lo, b_end, p);
+			from = 2;
+		} else {
+			if (maxlen < 4) break;
+			const uint32_t x2 = ((uint32_t)d[p + 2] << 8) | d[p + 3];
+			const uint32_t qa = gs_lower_u16(c.quad_nx, b_lo, b_end, x2);
+			const uint32_t qb = gs_lower_u16(c.quad_nx, qa, b_end, x2 + 1u);
+			pos_arr = c.quad_pos; lo = qa;
+			hi = gs_lower_u32(pos_arr, qa, qb, p);
+			from = 4;
+		}
+		for (uint32_t i = hi, taken = 0; i > lo && taken < cand; taken++) {
+			const uint32_t q = pos_arr[--i];
+			if (p - q - 1u >= c.dict_limit) break; /* ascending positions: everything further is outside too */
+			uint32_t len = from;
+			while (len < maxlen && d[q + len] == d[p + len]) len++;
+			if (len > best_len || (len == best_len && q > best_q)) { best_len = len; best_q = q; }
+		}
+	}
+	const uint32_t dist = p - best_q; /* real distance */
+	if (!(best_len >= 4 || (best_len == 3 && dist <= (1u << 14)) || (best_len == 2 && dist <= 128u))) best_len = 0;
+	*q_out = best_q;
+	return best_len;
+}
 __global__ void __launch_bounds__(256) k_greedy_seed(DevCtx c, mgl_pk* slab, uint32_t cand)
 {
 	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= c.n) return;
 	mgl_pk pk = MGL_PK_LITERAL;
 	if (p > 0 && p + 1 < c.n) {
-		const uint8_t* d = c.data;
-		const uint32_t maxlen = (c.n - p) < MGL_MAX_MATCH ? (c.n - p) : MGL_MAX_MATCH;
-		const uint32_t bigram = ((uint32_t)d[p] << 8) | d[p + 1];
-		const uint32_t b_lo = c.bucket_off[bigram], b_end = c.bucket_off[bigram + 1];
-		uint32_t best_len = 0, best_q = 0;
-		for (int src = 0; src < 2; src++) {
-			const uint32_t* pos_arr;
-			uint32_t lo, hi, from;
-			if (src == 0) {
-				pos_arr = c.bucket_pos; lo = b_lo;
-				hi = gs_lower_u32(pos_arr, b_lo, b_end, p);
-				from = 2;
-			} else {
-				if (maxlen < 4) break;
-				const uint32_t x2 = ((uint32_t)d[p + 2] << 8) | d[p + 3];
-				const uint32_t qa = gs_lower_u16(c.quad_nx, b_lo, b_end, x2);
-				const uint32_t qb = gs_lower_u16(c.quad_nx, qa, b_end, x2 + 1u);
-				pos_arr = c.quad_pos; lo = qa;
-				hi = gs_lower_u32(pos_arr, qa, qb, p);
-				from = 4;
-			}
-			for (uint32_t i = hi, taken = 0; i > lo && taken < cand; taken++) {
-				const uint32_t q = pos_arr[--i];
-				if (p - q - 1u >= c.dict_limit) break; /* ascending positions: everything further is outside too */
-				uint32_t len = from;
-				while (len < maxlen && d[q + len] == d[p + len]) len++;
-				if (len > best_len || (len == best_len && q > best_q)) { best_len = len; best_q = q; }
-			}
-		}
-		const uint32_t dist = p - best_q; /* real distance */
-		if (best_len >= 4 || (best_len == 3 && dist <= (1u << 14)) || (best_len == 2 && dist <= 128u))
-			pk = mgl_pack(MGL_MATCH, dist - 1u, best_len);
+		uint32_t q = 0, q1 = 0;
+		const uint32_t len = gs_best(c, p, cand, &q);
+		/* lazy step: a literal here if the next position starts a longer match */
+		const uint32_t len1 = (len != 0 && p + 2 < c.n) ? gs_best(c, p + 1, cand, &q1) : 0u;
+		if (len != 0 && len1 <= len) pk = mgl_pack(MGL_MATCH, p - q - 1u, len);
 	}
 	slab[p] = pk;
 }

@@ -19,9 +19,10 @@ LIT, MATCH = 1, 2
 def greedy_rule(data: bytes, cand: int, dict_limit: int = 0x400000):
     """The rule of mgl_index.hip:k_greedy_seed, position by position: candidates = the `cand`
     nearest earlier positions with the same 2 bytes + the `cand` nearest with the same 4 bytes,
-    inside the window; longest wins, nearest among equals; short matches only when near."""
+    inside the window; longest wins, nearest among equals; short matches only when near; and a
+    literal instead when the next position starts a longer match (lazy step)."""
     n = len(data)
-    out = [(LIT, 0, 1)] * n
+    best = [(0, 0)] * n  # (length, distance) of the match each position would take, (0, 0) = none
     by2, by4 = {}, {}
     for p in range(n):
         if 0 < p < n - 1:
@@ -40,12 +41,18 @@ def greedy_rule(data: bytes, cand: int, dict_limit: int = 0x400000):
                     best_len, best_q = ln, q
             dist = p - best_q
             if best_len >= 4 or (best_len == 3 and dist <= 1 << 14) or (best_len == 2 and dist <= 128):
-                out[p] = (MATCH, dist - 1, best_len)
+                best[p] = (best_len, dist)
         # the index holds every position that has a following byte (substring_enumerator.c:39-46)
         if p + 1 < n:
             by2.setdefault(data[p:p + 2], []).append(p)
         if p + 3 < n:
             by4.setdefault(data[p:p + 4], []).append(p)
+    out = [(LIT, 0, 1)] * n
+    for p in range(n):
+        ln, dist = best[p]
+        nxt = best[p + 1][0] if p + 2 < n else 0
+        if ln and nxt <= ln:
+            out[p] = (MATCH, dist - 1, ln)
     return out
 
 
@@ -84,6 +91,19 @@ def test_greedy_tail_entries_with_short_lookahead():
     got = as_list(cur)
     assert got == greedy_rule(data, 64)
     assert got[4] == (MATCH, 3, 6) and got[8] == (MATCH, 3, 2) and got[9] == (LIT, 0, 1)
+
+
+def test_greedy_lazy_step():
+    """'bcde' occurs earlier and so does 'abc': at the 'a' the next position starts a longer match,
+    so the 'a' stays a literal."""
+    data = b"abcX" + b"bcdefgY" + b"abcdefg"
+    sa = binding.SA(data, neighbours_per_step=16)
+    sa.seed_greedy(64)
+    cur, _ = sa.current()
+    got = as_list(cur)
+    assert got == greedy_rule(data, 64)
+    assert got[11] == (LIT, 0, 1) and got[12] == (MATCH, 7, 6)
+    sa.close()
     sa.close()
 
 

@@ -203,3 +203,28 @@ def test_cli_temperature(tmp_path):
                        capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-400:]
     assert lzma.decompress(r.stdout, format=lzma.FORMAT_ALONE) == data
+
+
+@pytest.mark.parametrize("kw", [dict(fullwalk=True), dict(snapshots=False), dict(serial_build=True), dict(lc=3, pb=2)],
+                         ids=["fullwalk", "no_snapshots", "serial_build", "lc3pb2"])
+def test_greedy_seed_under_every_engine_option(kw):
+    """The seed and the search from it do not depend on the engine options (and work with lc/pb != 0):
+    same slab, same costs as the default engine, step by step; epochs restart from the best slab."""
+    data = corpus.enwik_like(5000, 0x38)
+    props = {k: v for k, v in kw.items() if k in ("lc", "pb")}
+    ref = binding.SA(data, neighbours_per_step=96, seed=21, iters_per_epoch=50, **props)
+    sa = binding.SA(data, neighbours_per_step=96, seed=21, iters_per_epoch=50, **kw)
+    for s in (ref, sa):
+        s.seed_greedy(48)
+    a, ca = ref.current()
+    b, cb = sa.current()
+    assert ca == cb and as_list(a) == as_list(b) == greedy_rule(data, 48)
+    for _ in range(3):
+        assert ref.run(10)["current_cost"] == sa.run(10)["current_cost"]
+    for s in (ref, sa):
+        s.begin_epoch(1, from_best=True)
+    assert ref.run(10)["best_cost"] == sa.run(10)["best_cost"]
+    bst, _ = sa.best()
+    assert lzma.decompress(binding.emit_stream(data, bst, **props), format=lzma.FORMAT_ALONE) == data
+    ref.close()
+    sa.close()

@@ -157,6 +157,13 @@ __device__ __forceinline__ uint32_t chain_lower_bound(const uint32_t* pos, uint3
 		}
 		lo = nlo; hi = nhi < nlo ? nlo : nhi;
 	}
-	while (lo < hi && pos[lo] < x) lo++;
-	return lo;
+	/* at most 8 entries left: all of them in one round trip; the ones below x are a prefix */
+	uint32_t below = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 8; i++) {
+		const bool in = lo + i < hi;
+		const uint32_t v = pos[in ? lo + i : lo];
+		below += (in && v < x) ? 1u : 0u;
+	}
+	return lo + below;
 }

@@ -263,17 +263,20 @@ __device__ __forceinline__ void changes_add(Changes& ch, const mgl_plan& pl, uin
 	ch.direct += INS ? d : -d;
 }
 
-/* first index >= start (and < n) whose key, masked, equals cx; n if none.  Eight 16-bit keys
- * per read (the lists are 16-byte aligned). */
+/* first index >= start (and < n) whose key, masked, equals cx; n if none.  Sixteen 16-bit keys
+ * per trip: two independent 16-byte reads (the lists are 16-byte aligned), so a scan waits for
+ * half as many LDS round trips. */
 __device__ __forceinline__ uint32_t next_with_ctx(const uint16_t* keys, uint32_t start, uint32_t n, uint32_t cx, uint32_t mask)
 {
 	uint32_t base = start & ~7u;
 	while (base < n) {
 		const uint4 q = *reinterpret_cast<const uint4*>(keys + base);
-		const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+		uint4 r = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); /* no context has this key */
+		if (base + 8u < n) r = *reinterpret_cast<const uint4*>(keys + base + 8u);
+		const uint32_t w[8] = { q.x, q.y, q.z, q.w, r.x, r.y, r.z, r.w };
 		uint32_t hit = 0;
 #pragma unroll
-		for (uint32_t e = 0; e < 8; e++) {
+		for (uint32_t e = 0; e < 16; e++) {
 			const uint32_t key = (w[e >> 1] >> ((e & 1u) * 16u)) & mask;
 			hit |= (key == cx ? 1u : 0u) << e;
 		}
@@ -282,7 +285,7 @@ __device__ __forceinline__ uint32_t next_with_ctx(const uint16_t* keys, uint32_t
 			const uint32_t idx = base + (uint32_t)__ffs((int)hit) - 1u;
 			return idx < n ? idx : n;
 		}
-		base += 8;
+		base += 16;
 	}
 	return n;
 }

@@ -657,7 +657,8 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	} else if ((MODE == MGL_NBR_FULL) != (ctl->nbr_single != 0)) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
-	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block) */
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	uint32_t j = j_base + blockIdx.x * (blockDim.x >> 6) + wid; /* [j_base, j_end): the slice of the step this launch covers */

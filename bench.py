@@ -216,6 +216,19 @@ def main():
                       "fallback_neighbours": st["fallback_neighbours"],
                       "second_pass_neighbours": st["second_pass_neighbours"]},
         }
+        if n <= (16 << 20):
+            # correctness gates reported with the number, after the timed region: the best slab's
+            # cost re-derived by the device's independent full walk, and its stream through liblzma
+            import lzma
+            best, best_cost = sa.best()
+            lcpb = {k: props[k] for k in ("lc", "lp", "pb") if k in props}
+            stream = binding.emit_stream(data, best, **lcpb)
+            try:
+                ok = lzma.decompress(stream, format=lzma.FORMAT_ALONE) == bytes(data)
+            except lzma.LZMAError:
+                ok = False
+            out["gates"] = {"best_cost_equals_full_walk": sa.cost_slab(best)["total"] == best_cost,
+                            "lzma_roundtrip": ok, "stream_bytes": len(stream)}
         traffic, src = pmc_traffic()
         if traffic is not None and args.config == "c2":
             out["roofline"]["traffic"] = traffic

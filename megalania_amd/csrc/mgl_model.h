@@ -317,7 +317,11 @@ MGL_HD void mgl_plan_event(const mgl_plan* p, uint32_t slot, uint32_t* ctx, uint
 /* probability_model.c:5-15 */
 MGL_HD uint32_t mgl_prob_update(uint32_t v, uint32_t bit)
 {
-	return bit ? v - (v >> 5) : v + ((2048u - v) >> 5);
+	/* bit ? v - (v >> 5) : v + ((2048 - v) >> 5), written so that the chain through v is three
+	 * operations deep (every re-simulation loop is a chain of these): -(v >> 5) == (31 - v) >> 5 with an
+	 * arithmetic shift, for every v in 0..2048 (checked exhaustively in tests/test_host.py) */
+	const int32_t c = bit ? 31 : 2048;
+	return (uint32_t)((int32_t)v + ((c - (int32_t)v) >> 5));
 }
 
 /* counter-based RNG of the batched SA semantics */

@@ -121,3 +121,18 @@ def test_cli_without_gpu_fails_loudly(tmp_path):
     assert r.returncode != 0 and b"no HIP device" in r.stderr and r.stdout == b""
     with pytest.raises(binding.MglError):
         binding.SA(b"hello hello")
+
+
+def test_probability_update_form_is_exact(tmp_path):
+    """mgl_prob_update is written branch-free ((c - v) >> 5 with an arithmetic shift); it must be the
+    reference's update (probability_model.c:5-15) for every probability and both bits, as compiled by
+    the host compiler (the device compiler sees the same header; the GPU parity tests cover it there)."""
+    src = tmp_path / "pu.c"
+    src.write_text('#include <stdint.h>\n#include "mgl_model.h"\n'
+                   "int main(void) { for (uint32_t v = 0; v <= 2048; v++) for (uint32_t b = 0; b < 2; b++) {\n"
+                   "  uint32_t ref = b ? v - (v >> 5) : v + ((2048u - v) >> 5);\n"
+                   "  if (mgl_prob_update(v, b) != ref) return 1; }\n  return 0; }\n")
+    exe = tmp_path / "pu"
+    inc = os.path.join(ROOT, "megalania_amd", "csrc")
+    subprocess.run([os.environ.get("CC", "gcc"), "-O2", "-I", inc, str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0

@@ -300,6 +300,9 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), 4096u + sa->per_wave_rest, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
 			                   sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
+			/* the second half's re-simulation, several wavefronts per neighbour */
+			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u, st, sa->ctx, sa->b2, sa->base.ctl,
+			                   sa->nbr, sa->big, j0, j1, sa->d_todo, sa->d_counts);
 		}
 		if (slices >= 2) {
 			HIPCHK(hipEventRecord(sa->ev_join, sa->stream2));
@@ -358,6 +361,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
 	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	dfree(sa->d_todo); dfree(sa->d_prof);
+	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
 	dfree(sa->d_todo2); dfree(sa->d_counts); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
@@ -602,6 +606,14 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
 		HIPCHK(hipMalloc(&sa->d_pickstate, sizeof(uint4) * 2 * K));
 		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;
+		if (sa->split_nbr) {
+			/* the second half's re-simulation as its own launch (k_sim): lists and headers per neighbour */
+			BigScratch& g = sa->big;
+			HIPCHK(hipMalloc(&g.sim_hdr, sizeof(uint4) * (size_t)K));
+			HIPCHK(hipMalloc(&g.sim_keys, sizeof(uint16_t) * 2u * MGL_CHG_CAP * (size_t)K));
+			HIPCHK(hipMalloc(&g.sim_pos, sizeof(uint32_t) * 2u * MGL_CHG_CAP * (size_t)K));
+			HIPCHK(hipMemset(g.sim_hdr, 0xFF, sizeof(uint4) * (size_t)K));
+		}
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
 		if (!sa->split_nbr) { /* one-kernel form only */
 			Control c0;

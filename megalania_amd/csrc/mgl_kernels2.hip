@@ -297,8 +297,8 @@ __device__ __forceinline__ uint32_t next_with_ctx(const uint16_t* keys, uint32_t
  * Returns sum(new cost - base cost) over the simulated spans (all lanes get the value).
  * If overlay != nullptr the probability each touched context has at `limit` is written into
  * it (contexts that re-coupled before `limit` keep the base value already there). */
-__device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uint32_t limit, uint16_t* overlay,
-                             uint32_t lane, bool* too_many)
+/* part A (one wavefront): the distinct touched contexts, ascending, into ch.uctx; returns how many */
+__device__ __forceinline__ uint32_t chain_list(Changes& ch, uint32_t lane, bool* too_many)
 {
 	const uint32_t m = ch.n_ins + ch.n_rem;
 	wave_sync();
@@ -330,9 +330,16 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 		nu += chunk;
 	}
 	wave_sync();
+	return nu;
+}
+/* part B: this lane's share of the contexts -- uctx[first + lane], then every `stride` further on
+ * (64 for a wavefront on its own; k_sim puts several wavefronts on one neighbour).  Returns the
+ * lane's own sum. */
+__device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& ch, const uint16_t* T, uint32_t limit, uint16_t* overlay,
+                                                      uint32_t lane, uint32_t first, uint32_t stride, uint32_t nu)
+{
 	int64_t delta = 0;
-	if (ch.diag == 41) return (int64_t)nu;
-	for (uint32_t base = 0; base < nu; base += 64) {
+	for (uint32_t base = first; base < nu; base += stride) {
 		if (base + lane >= nu) continue;
 		const uint32_t cx = ch.uctx[base + lane];
 		uint32_t ii = next_with_ctx(ch.ins_key, 0, ch.n_ins, cx, 0x7FFFu);
@@ -451,6 +458,15 @@ __device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uin
 		if (overlay && (at_limit || (limit != MGL_POS_INF && cpos[k] == MGL_POS_INF))) overlay[cx] = (uint16_t)p;
 		(void)c_base;
 	}
+	return delta;
+}
+__device__ int64_t chain_sim(const Base2& b, Changes& ch, const uint16_t* T, uint32_t limit, uint16_t* overlay,
+                             uint32_t lane, bool* too_many)
+{
+	const uint32_t nu = chain_list(ch, lane, too_many);
+	if (*too_many) return 0;
+	if (ch.diag == 41) return (int64_t)nu;
+	const int64_t delta = chain_sim_contexts(b, ch, T, limit, overlay, lane, 0u, 64u, nu);
 	/* signed wave sum */
 	uint64_t u = (uint64_t)delta;
 	u = wave_sum64(u);
@@ -628,6 +644,11 @@ struct BigScratch {
 	uint32_t cap, uctx_cap, slots;
 	const uint32_t* todo_in; const uint32_t* todo_in_count;
 	uint32_t* spill_ctr; /* slots handed out to first-pass wavefronts that had to spill their lists */
+	/* re-simulation handed to k_sim (several wavefronts per neighbour): per neighbour a header
+	 * {n_ins, n_rem, direct lo, direct hi} (n_ins = ~0: nothing to do) and the two change lists */
+	uint4* sim_hdr;
+	uint16_t* sim_keys; /* per neighbour: ins_key[MGL_CHG_CAP] | rem_key[MGL_CHG_CAP] */
+	uint32_t* sim_pos;  /* per neighbour: ins_pos[MGL_CHG_CAP] | rem_pos[MGL_CHG_CAP] */
 };
 /* MODE: the regular launch is split in two so that each half needs fewer registers and more
  * wavefronts fit a SIMD (top-K is the register hog):
@@ -716,6 +737,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	 * launch takes both from the first half's record instead of drawing and searching again */
 	uint32_t target;
 	mgl_wstate nb; /* neighbour's walk state */
+	if (MODE == MGL_NBR_REST && lane == 0) big.sim_hdr[j] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
 	if (MODE == MGL_NBR_REST) {
 		const uint4 s0 = pickstate[2u * j], s1 = pickstate[2u * j + 1u];
 		target = s0.x; rng.n = s0.y;
@@ -797,7 +819,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	uint32_t sim_limit = MGL_POS_INF;
 	bool sim_overlay = false;
 	int64_t delta = 0;
-	bool generate_failed = false;
+	bool generate_failed = false, sim_deferred = false;
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
 	bool first_packet = true;
@@ -847,7 +869,19 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 			if ((ch.n_ins + ch.n_rem) != 0) { sim_limit = pick_pos; sim_overlay = true; phase = P_SIM; }
 			else phase = P_TOPK;
 		}
-		if (MODE != MGL_NBR_PICK && phase == P_SIM) {
+		if (MODE == MGL_NBR_REST && phase == P_SIM) {
+			/* the second half ends here (always: it holds no re-simulation code of its own): the lists go to k_sim, which puts several wavefronts on the
+			 * contexts of one neighbour and writes the cost; journal and counters are written below */
+			uint16_t* gk = big.sim_keys + (size_t)j * (2u * MGL_CHG_CAP);
+			uint32_t* gp = big.sim_pos + (size_t)j * (2u * MGL_CHG_CAP);
+			for (uint32_t e = lane; e < ch.n_ins; e += 64) { gk[e] = ch.ins_key[e]; gp[e] = ch.ins_pos[e]; }
+			for (uint32_t e = lane; e < ch.n_rem; e += 64) { gk[MGL_CHG_CAP + e] = ch.rem_key[e]; gp[MGL_CHG_CAP + e] = ch.rem_pos[e]; }
+			if (lane == 0) big.sim_hdr[j] = make_uint4(ch.n_ins, ch.n_rem, (uint32_t)(uint64_t)ch.direct, (uint32_t)((uint64_t)ch.direct >> 32));
+			sim_deferred = true;
+			phase = P_OUT;
+			continue;
+		}
+		if (MODE == MGL_NBR_FULL && phase == P_SIM) {
 			const int64_t r = chain_sim(b, ch, T, sim_limit, (MODE != MGL_NBR_REST && sim_overlay) ? probs : nullptr, lane, &too_many);
 			wave_sync();
 			if (too_many) { phase = P_OUT; continue; }
@@ -1030,8 +1064,79 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 		}
 		nd++;
 	}
-	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; }
+	if (lane == 0) { if (!sim_deferred) out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; }
 	if (prof_acc && lane == 0) /* diagnostic: wave lifetime (40 bits) | change events (12 bits) | packets walked (12 bits) */
 		prof_acc[32 + j] = ((__builtin_readcyclecounter() - t_begin) & 0xFFFFFFFFFFull) |
 		                   ((unsigned long long)((ch.n_ins + ch.n_rem) & 0xFFFu) << 40) | ((unsigned long long)(walked & 0xFFFu) << 52);
+}
+
+
+/* ================================================================== k_sim
+ *
+ * The re-simulation of the split launch's second half, as its own launch: MGL_SIM_WAVES wavefronts
+ * per neighbour share its touched contexts (one context per lane, as in chain_sim), so a neighbour
+ * with 150 contexts is one trip instead of three.  The second half's duration is its slowest
+ * wavefront (the mean one lives a third of that), and the slowest are the ones with many contexts.
+ * Small kernel: no walk state, no journal -- 64 VGPRs less than the second half. */
+#ifndef MGL_SIM_WAVES
+#define MGL_SIM_WAVES 2u
+#endif
+__global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
+                                                           uint32_t* todo, uint32_t* todo_count)
+{
+	if (ctl->nbr_single != 0) return; /* the one-kernel form ran this step: it re-simulates on its own */
+	const uint32_t j = j_base + blockIdx.x;
+	if (j >= j_end) return;
+	const uint4 hdr = big.sim_hdr[j];
+	if (hdr.x == 0xFFFFFFFFu) return; /* failed, dropped or handed to the second pass: its cost is written */
+	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
+	__shared__ __attribute__((aligned(16))) uint32_t s_pos[2 * MGL_CHG_CAP];
+	__shared__ __attribute__((aligned(16))) uint16_t s_key[2 * MGL_CHG_CAP];
+	__shared__ __attribute__((aligned(16))) uint16_t s_uctx[2 * MGL_CHG_CAP];
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[]; /* one bit per context: sized by the launch */
+	__shared__ unsigned long long s_sum[MGL_SIM_WAVES];
+	__shared__ uint32_t s_nu, s_many;
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
+	Changes ch;
+	ch.n_ins = hdr.x; ch.n_rem = hdr.y;
+	ch.ins_pos = s_pos; ch.rem_pos = s_pos + MGL_CHG_CAP;
+	ch.ins_key = s_key; ch.rem_key = s_key + MGL_CHG_CAP;
+	ch.uctx = s_uctx; ch.ctxbits = s_bits;
+	ch.cap = MGL_CHG_CAP; ch.uctx_cap = 2 * MGL_CHG_CAP;
+	ch.nbitwords = (c.L.total + 31u) >> 5;
+	ch.direct = 0; ch.dbg = nullptr; ch.diag = c.diag_stop; ch.overflow = false;
+	{
+		const uint16_t* gk = big.sim_keys + (size_t)j * (2u * MGL_CHG_CAP);
+		const uint32_t* gp = big.sim_pos + (size_t)j * (2u * MGL_CHG_CAP);
+		for (uint32_t e = threadIdx.x; e < ch.n_ins; e += blockDim.x) { s_key[e] = gk[e]; s_pos[e] = gp[e]; }
+		for (uint32_t e = threadIdx.x; e < ch.n_rem; e += blockDim.x) { s_key[MGL_CHG_CAP + e] = gk[MGL_CHG_CAP + e]; s_pos[MGL_CHG_CAP + e] = gp[MGL_CHG_CAP + e]; }
+	}
+	__syncthreads();
+	if (wid == 0) {
+		bool too_many = false;
+		const uint32_t nu = chain_list(ch, lane, &too_many);
+		if (lane == 0) { s_nu = nu; s_many = too_many ? 1u : 0u; }
+	}
+	__syncthreads();
+	if (s_many) { /* more distinct contexts than the list holds: the second pass, as the second half would have done */
+		if (threadIdx.x == 0) {
+			const uint32_t slot2 = atomicAdd(todo_count, 1u);
+			todo[slot2] = j;
+			atomicAdd((unsigned long long*)&ctl->big_nbrs, 1ull);
+			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
+		}
+		return;
+	}
+	if (c.diag_stop == 41) { if (threadIdx.x == 0) out.cost[j] = s_nu; return; } /* diagnostic: listing only */
+	const int64_t mine = chain_sim_contexts(b, ch, T, MGL_POS_INF, nullptr, lane, wid * 64u, 64u * MGL_SIM_WAVES, s_nu);
+	const uint64_t u = wave_sum64((uint64_t)mine);
+	if (lane == 0) s_sum[wid] = u;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint64_t d = 0;
+		for (uint32_t w = 0; w < MGL_SIM_WAVES; w++) d += s_sum[w];
+		const int64_t direct = (int64_t)((uint64_t)hdr.z | ((uint64_t)hdr.w << 32));
+		out.cost[j] = (uint64_t)((int64_t)ctl->rebuild_cost + (int64_t)d + direct);
+	}
 }

@@ -203,7 +203,7 @@ def main():
                        "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_neighbours2<PICK> + k_neighbours2<REST> (the two halves of the incremental neighbour evaluation; + second pass)", "avg_launch_ms": avg_ms,
+                         "kernel": "k_neighbours2<PICK> + k_neighbours2<REST> + k_sim (pick, window walk and re-simulation of the incremental neighbour evaluation; + second pass)", "avg_launch_ms": avg_ms,
                          "launches_timed": launches,
                          "note": "achieved = evaluations/launch x (N + 12 P) / launch time: algorithmic bytes of the "
                                  "metric's unit (one exact whole-parse cost); the kernel prices only the changed window",

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the two halves of the neighbour launch (k_neighbours2<false, 1|2>) per step, the way MI355X_MICROARCH.md prescribes: counters in
+# HBM traffic of the three kernels of the regular neighbour launch (k_neighbours2<false, 1|2> + k_sim) per step, the way MI355X_MICROARCH.md prescribes: counters in
 # their own rocprofv3 passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2), no trace domains mixed in.
 # Usage (on the GPU box, from the repo root):  bash tools/collect_pmc.sh
 set -e
@@ -12,13 +12,13 @@ python3 - <<PY
 import csv, glob, json
 def avg(d, counter):
     rows = [r for f in glob.glob("$ROOT/gpurun_out/" + d + "/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))
-            if "k_neighbours2<false" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    # the regular neighbour launch is two kernels (pick + rest) per step: sum both, per step
+            if ("k_neighbours2<false" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_sim")) and r["Counter_Name"] == counter]
+    # the regular neighbour launch is three kernels (pick + rest + re-simulation) per step: sum them, per step
     steps = len({r["Dispatch_Id"] for r in rows if "<false, 2>" in r["Kernel_Name"]}) or len({r["Dispatch_Id"] for r in rows})
     return sum(float(r["Counter_Value"]) for r in rows) / max(1, steps), steps
 f, nf = avg("pmc_fetch", "FETCH_SIZE")
 w, nw = avg("pmc_write", "WRITE_SIZE")
-out = dict(kernel="k_neighbours2<false, PICK> + k_neighbours2<false, REST>", workload="c2, 4096 neighbours/launch, after 300 warm-up steps", launches=nf,
+out = dict(kernel="k_neighbours2<false, PICK> + k_neighbours2<false, REST> + k_sim", workload="c2, 4096 neighbours/launch, after 300 warm-up steps", launches=nf,
            FETCH_SIZE_KB=f, WRITE_SIZE_KB=w,
            note="FETCH_SIZE/WRITE_SIZE are in KB (rocprofv3 derived metrics).  On gfx950 FETCH_SIZE counts 128-B requests as 64 B "
                 "for wide streaming reads (MI355X_MICROARCH.md, HBM); this kernel reads narrow scattered lines, so both the raw "

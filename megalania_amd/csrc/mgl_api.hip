@@ -89,6 +89,7 @@ struct mgl_sa {
 	unsigned long long* d_prof; /* 16 u64: per-phase cycles + counts, only with MGL_F_PROFILE */
 	uint32_t* d_todo;       /* [0] = count, [1..K] = neighbour indices for the full-walk fallback */
 	uint32_t per_wave2, waves_per_block2, nbr2_lds, build_lds;
+	uint32_t chg_cap = MGL_CHG_CAP; /* events per first-pass list */
 	uint32_t per_wave_pick, per_wave_rest, pick_waves; /* LDS per wavefront of the two halves of the split launch */
 	size_t b2_bytes;
 	BigScratch big;
@@ -301,7 +302,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
 			                   sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
 			/* the second half's re-simulation, several wavefronts per neighbour */
-			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u, st, sa->ctx, sa->b2, sa->base.ctl,
+			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u, st, sa->ctx, sa->b2, sa->base.ctl,
 			                   sa->nbr, sa->big, j0, j1, sa->d_todo, sa->d_counts);
 		}
 		if (slices >= 2) {
@@ -564,7 +565,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			/* journal + context bitmap + max(model + price tables, change lists + context list) */
 			const uint32_t fixed = MGL_MAX_DIFFS * (8u + 8u + 4u) + (((((L.total + 31u) >> 5) + 3u) & ~3u) * 4u) ;
 			const uint32_t model = ckpt_elems * 2u + MGL_PRICE_WORDS * 4u;
-			const uint32_t lists = MGL_CHG_CAP * (4u + 4u + 2u + 2u) + 2u * MGL_CHG_CAP * 2u;
+			/* first-pass list size: a step of few neighbours leaves most of the LDS idle, and on repetitive inputs
+			 * (long matches everywhere) windows are long: give the lists the room */
+			sa->chg_cap = K <= 1024u ? 4u * MGL_CHG_CAP : (K <= 2048u ? 2u * MGL_CHG_CAP : MGL_CHG_CAP);
+			const uint32_t lists = sa->chg_cap * (4u + 4u + 2u + 2u) + 2u * sa->chg_cap * 2u;
 			sa->per_wave2 = (fixed + (model > lists ? model : lists) + 15u) & ~15u;
 			sa->per_wave_pick = (model + 15u) & ~15u; /* no journal / bitmap in the pick half */
 			sa->per_wave_rest = (fixed + lists + 15u) & ~15u;
@@ -572,6 +576,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		{
 			BigScratch& g = sa->big;
 			memset(&g, 0, sizeof g);
+			g.chg_cap = sa->chg_cap;
 			g.cap = MGL_BIG_CAP; g.uctx_cap = ckpt_elems; g.slots = (uint32_t)(K > 512 ? K : 512); /* every neighbour of a step may need one */
 			HIPCHK(hipMalloc(&g.ins_key, sizeof(uint16_t) * (size_t)g.cap * g.slots));
 			HIPCHK(hipMalloc(&g.rem_key, sizeof(uint16_t) * (size_t)g.cap * g.slots));
@@ -610,8 +615,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			/* the second half's re-simulation as its own launch (k_sim): lists and headers per neighbour */
 			BigScratch& g = sa->big;
 			HIPCHK(hipMalloc(&g.sim_hdr, sizeof(uint4) * (size_t)K));
-			HIPCHK(hipMalloc(&g.sim_keys, sizeof(uint16_t) * 2u * MGL_CHG_CAP * (size_t)K));
-			HIPCHK(hipMalloc(&g.sim_pos, sizeof(uint32_t) * 2u * MGL_CHG_CAP * (size_t)K));
+			HIPCHK(hipMalloc(&g.sim_keys, sizeof(uint16_t) * 2u * sa->chg_cap * (size_t)K));
+			HIPCHK(hipMalloc(&g.sim_pos, sizeof(uint32_t) * 2u * sa->chg_cap * (size_t)K));
 			HIPCHK(hipMemset(g.sim_hdr, 0xFF, sizeof(uint4) * (size_t)K));
 		}
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;

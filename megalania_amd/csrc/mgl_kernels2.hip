@@ -646,9 +646,10 @@ struct BigScratch {
 	uint32_t* spill_ctr; /* slots handed out to first-pass wavefronts that had to spill their lists */
 	/* re-simulation handed to k_sim (several wavefronts per neighbour): per neighbour a header
 	 * {n_ins, n_rem, direct lo, direct hi} (n_ins = ~0: nothing to do) and the two change lists */
+	uint32_t chg_cap; /* events per first-pass list (MGL_CHG_CAP, more when a step has few neighbours and LDS to spare) */
 	uint4* sim_hdr;
-	uint16_t* sim_keys; /* per neighbour: ins_key[MGL_CHG_CAP] | rem_key[MGL_CHG_CAP] */
-	uint32_t* sim_pos;  /* per neighbour: ins_pos[MGL_CHG_CAP] | rem_pos[MGL_CHG_CAP] */
+	uint16_t* sim_keys; /* per neighbour: ins_key[chg_cap] | rem_key[chg_cap] */
+	uint32_t* sim_pos;  /* per neighbour: ins_pos[chg_cap] | rem_pos[chg_cap] */
 };
 /* MODE: the regular launch is split in two so that each half needs fewer registers and more
  * wavefronts fit a SIMD (top-K is the register hog):
@@ -711,11 +712,11 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	uint16_t* probs = (uint16_t*)uni_base;
 	uint32_t* lencost = (uint32_t*)(uni_base + (size_t)b.ck_elems * 2);
 	ch.ins_pos = (uint32_t*)uni_base;
-	ch.rem_pos = ch.ins_pos + MGL_CHG_CAP;
-	ch.ins_key = (uint16_t*)(ch.rem_pos + MGL_CHG_CAP);
-	ch.rem_key = ch.ins_key + MGL_CHG_CAP;
-	ch.uctx = ch.rem_key + MGL_CHG_CAP;
-	ch.cap = MGL_CHG_CAP; ch.uctx_cap = 2 * MGL_CHG_CAP;
+	ch.rem_pos = ch.ins_pos + big.chg_cap;
+	ch.ins_key = (uint16_t*)(ch.rem_pos + big.chg_cap);
+	ch.rem_key = ch.ins_key + big.chg_cap;
+	ch.uctx = ch.rem_key + big.chg_cap;
+	ch.cap = big.chg_cap; ch.uctx_cap = 2 * big.chg_cap;
 	if (BIG) {
 		if (slot >= big.slots) { /* more flagged neighbours than scratch slots: full walk */
 			if (lane == 0) { const uint32_t s2 = atomicAdd(todo_count, 1u); todo[s2] = j; }
@@ -872,10 +873,10 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 		if (MODE == MGL_NBR_REST && phase == P_SIM) {
 			/* the second half ends here (always: it holds no re-simulation code of its own): the lists go to k_sim, which puts several wavefronts on the
 			 * contexts of one neighbour and writes the cost; journal and counters are written below */
-			uint16_t* gk = big.sim_keys + (size_t)j * (2u * MGL_CHG_CAP);
-			uint32_t* gp = big.sim_pos + (size_t)j * (2u * MGL_CHG_CAP);
+			uint16_t* gk = big.sim_keys + (size_t)j * (2u * big.chg_cap);
+			uint32_t* gp = big.sim_pos + (size_t)j * (2u * big.chg_cap);
 			for (uint32_t e = lane; e < ch.n_ins; e += 64) { gk[e] = ch.ins_key[e]; gp[e] = ch.ins_pos[e]; }
-			for (uint32_t e = lane; e < ch.n_rem; e += 64) { gk[MGL_CHG_CAP + e] = ch.rem_key[e]; gp[MGL_CHG_CAP + e] = ch.rem_pos[e]; }
+			for (uint32_t e = lane; e < ch.n_rem; e += 64) { gk[big.chg_cap + e] = ch.rem_key[e]; gp[big.chg_cap + e] = ch.rem_pos[e]; }
 			if (lane == 0) big.sim_hdr[j] = make_uint4(ch.n_ins, ch.n_rem, (uint32_t)(uint64_t)ch.direct, (uint32_t)((uint64_t)ch.direct >> 32));
 			sim_deferred = true;
 			phase = P_OUT;
@@ -1090,27 +1091,30 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b
 	const uint4 hdr = big.sim_hdr[j];
 	if (hdr.x == 0xFFFFFFFFu) return; /* failed, dropped or handed to the second pass: its cost is written */
 	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
-	__shared__ __attribute__((aligned(16))) uint32_t s_pos[2 * MGL_CHG_CAP];
-	__shared__ __attribute__((aligned(16))) uint16_t s_key[2 * MGL_CHG_CAP];
-	__shared__ __attribute__((aligned(16))) uint16_t s_uctx[2 * MGL_CHG_CAP];
-	extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[]; /* one bit per context: sized by the launch */
+	/* sized by the launch: one bit per context, then the two lists (positions, keys) and the context list */
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+	const uint32_t cap = big.chg_cap;
+	uint32_t* s_bits = s_dyn;
+	uint32_t* s_pos = s_dyn + ((((c.L.total + 31u) >> 5) + 3u) & ~3u);
+	uint16_t* s_key = (uint16_t*)(s_pos + 2u * cap);
+	uint16_t* s_uctx = s_key + 2u * cap;
 	__shared__ unsigned long long s_sum[MGL_SIM_WAVES];
 	__shared__ uint32_t s_nu, s_many;
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
 	Changes ch;
 	ch.n_ins = hdr.x; ch.n_rem = hdr.y;
-	ch.ins_pos = s_pos; ch.rem_pos = s_pos + MGL_CHG_CAP;
-	ch.ins_key = s_key; ch.rem_key = s_key + MGL_CHG_CAP;
+	ch.ins_pos = s_pos; ch.rem_pos = s_pos + cap;
+	ch.ins_key = s_key; ch.rem_key = s_key + cap;
 	ch.uctx = s_uctx; ch.ctxbits = s_bits;
-	ch.cap = MGL_CHG_CAP; ch.uctx_cap = 2 * MGL_CHG_CAP;
+	ch.cap = cap; ch.uctx_cap = 2 * cap;
 	ch.nbitwords = (c.L.total + 31u) >> 5;
 	ch.direct = 0; ch.dbg = nullptr; ch.diag = c.diag_stop; ch.overflow = false;
 	{
-		const uint16_t* gk = big.sim_keys + (size_t)j * (2u * MGL_CHG_CAP);
-		const uint32_t* gp = big.sim_pos + (size_t)j * (2u * MGL_CHG_CAP);
+		const uint16_t* gk = big.sim_keys + (size_t)j * (2u * cap);
+		const uint32_t* gp = big.sim_pos + (size_t)j * (2u * cap);
 		for (uint32_t e = threadIdx.x; e < ch.n_ins; e += blockDim.x) { s_key[e] = gk[e]; s_pos[e] = gp[e]; }
-		for (uint32_t e = threadIdx.x; e < ch.n_rem; e += blockDim.x) { s_key[MGL_CHG_CAP + e] = gk[MGL_CHG_CAP + e]; s_pos[MGL_CHG_CAP + e] = gp[MGL_CHG_CAP + e]; }
+		for (uint32_t e = threadIdx.x; e < ch.n_rem; e += blockDim.x) { s_key[cap + e] = gk[cap + e]; s_pos[cap + e] = gp[cap + e]; }
 	}
 	__syncthreads();
 	if (wid == 0) {

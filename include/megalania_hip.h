@@ -178,7 +178,8 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
  * counters, 15 pick records, 16 the control block.
  * mgl_debug_set: key 0 = stop the neighbour kernels after a phase (tools/phase_cost.py), 50 =
  * stage timing in the accept path; key 1 = make the parallel builder redo every chain segment
- * serially (exercises its fallback). */
+ * serially (exercises its fallback); key 2 = shrink the first-pass change lists (a multiple of 8,
+ * at most the allocated size) so that neighbours overflow into the second pass (exercises it). */
 int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes);
 int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value);
 /* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the

@@ -1090,5 +1090,10 @@ extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
 	if (!sa) return fail(MGL_EINVAL, "null handle");
 	if (key == 0) { sa->ctx.diag_stop = (uint32_t)value; return MGL_OK; }
 	if (key == 1) { sa->pb.force_fix = (uint32_t)value; return MGL_OK; } /* parallel builder: redo every chain segment serially */
+	if (key == 2) { /* first-pass list capacity, below what was allocated: pushes neighbours into the second pass */
+		if (value < 8 || value > sa->chg_cap || (value & 7u)) return fail(MGL_EINVAL, "mgl_debug_set: list capacity must be a multiple of 8 within the allocated one");
+		sa->big.chg_cap = (uint32_t)value;
+		return MGL_OK;
+	}
 	return fail(MGL_EINVAL, "mgl_debug_set: unknown key");
 }

@@ -303,3 +303,26 @@ def test_launch_forms_give_one_trajectory(monkeypatch):
     assert (a == c).all() and (b == c).all()
     for x in (adaptive, split, single):
         x.close()
+
+
+def test_second_pass_takes_what_overflows_small_lists():
+    """The first-pass change lists are sized by the step (1 024 events each way for small steps), so
+    small tests rarely overflow them.  Shrunk to 16 events (mgl_debug_set key 2) most neighbours go
+    through the second pass (lists in global memory) -- the trajectory must not notice."""
+    data = corpus.lorem(3000)
+    runs = []
+    for cap in (0, 16):
+        sa = binding.SA(data, neighbours_per_step=96, seed=5, iters_per_epoch=60)
+        if cap:
+            assert sa.L.mgl_debug_set(sa.h, 2, cap) == 0
+        costs, second = [], 0
+        for _ in range(40):
+            st = sa.run(1)
+            costs.append(st["current_cost"])
+            second += st["second_pass_neighbours"]
+        cur, cost = sa.current()
+        runs.append((costs, cost, [tuple(int(x) for x in r) for r in zip(cur["type"], cur["dist"], cur["len"])], second))
+        assert sa.L.mgl_debug_set(sa.h, 2, 12) != 0  # not a multiple of 8
+        sa.close()
+    assert runs[0][:3] == runs[1][:3]
+    assert runs[1][3] > 2 * runs[0][3] and runs[1][3] > 40 * 96 // 2  # most of the 3 840 neighbours took the second pass

@@ -68,15 +68,11 @@ def build_host(force=False):
     return HOST_SO
 
 
-def build_oracle():
-    """Test infrastructure: the CPU oracle and, where /root/reference exists, the reference."""
-    _run(["make", "-C", os.path.join(ROOT, "oracle")])
-
-
 def build_all(force=False):
+    """The product's native pieces only.  The test-side checkers (oracle/) are built by
+    tools/build_oracle.py -- nothing in this package knows about them."""
     build_hip(force)
     build_host(force)
-    build_oracle()
 
 
 if __name__ == "__main__":

@@ -25,6 +25,9 @@ def pytest_sessionstart(session):
         return
     from megalania_amd import build as _build
     _build.build_all()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_oracle
+    build_oracle.build_oracle()
 
 
 def sha(a) -> str:

@@ -98,7 +98,24 @@ typedef struct {
 	uint64_t full_rebuilds;       /* accepted steps whose base update fell back to a full rebuild */
 	uint64_t fallback_neighbours; /* neighbours costed by the full-walk kernel instead of incrementally */
 	uint64_t second_pass_neighbours; /* neighbours redone incrementally with their lists in global memory */
+	uint64_t bulk_steps;          /* steps that took every window-best acceptable neighbour (mgl_sa_set_accept_mode) */
+	uint64_t dropped_neighbours;  /* generates dropped because their journal outgrew 64 slab entries (counted in `failed`;
+	                               * the reference's undo stack grows without bound, packet_slab_undo_stack.c:70-77) */
+	uint64_t improving_neighbours;/* evaluations that cost less than the slab they were made from */
 } mgl_sa_stats;
+
+/* How a step of K costed neighbours moves the chain (the reference decides after every single
+ * evaluation, main.c:86-96; see DESIGN.md section 4 for the batched rule both modes share):
+ *   MGL_ACCEPT_SINGLE  the best acceptable neighbour of the step (base structures updated in place);
+ *   MGL_ACCEPT_BULK    every acceptable neighbour that is the best of its own window -- hundreds to
+ *                      thousands of moves per step while the slab is young -- followed by a parallel
+ *                      rebuild of the base structures, which also yields the new slab's exact cost;
+ *   MGL_ACCEPT_AUTO    (default) bulk steps while a step offers at least `bulk_threshold` improving
+ *                      neighbours on average, single steps otherwise; decided per block of steps from
+ *                      device counters only, so a run is reproducible.  bulk_threshold 0 = default. */
+#define MGL_ACCEPT_AUTO 0
+#define MGL_ACCEPT_SINGLE 1
+#define MGL_ACCEPT_BULK 2
 
 typedef struct {
 	uint32_t position;
@@ -138,6 +155,9 @@ int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates);
  * t_eff * T[u], u in 1..2047, t_eff = temperature * (iters_per_epoch - i) / iters_per_epoch
  * (linear cooling inside the epoch).  Must be below 2^40. */
 int mgl_sa_set_temperature(mgl_sa* sa, uint64_t temperature);
+int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_threshold);
+/* The modes of the steps of the last mgl_sa_run (0 single, 1 bulk), for replaying a run elsewhere. */
+int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, size_t* count);
 /* Adopt a best slab found elsewhere (another chain / GPU): replaces best slab and best cost.
  * `perplexity` must be the slab's exact cost (it is re-derived on the device and checked). */
 int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t perplexity);
@@ -175,7 +195,7 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
  * 4 on-walk bitmap, 5 special bitmap, 6 special-state records, 7 dense checkpoints, 8 chain
  * capacities, 9 phase-cycle counters (MGL_F_PROFILE), 10 per-step overflow / repair counters,
  * 11 parallel-builder totals, 12 / 13 match index (bucket offsets / positions), 14 accept-path
- * counters, 15 pick records, 16 the control block.
+ * counters, 15 pick records, 16 the control block, 21 the windows (target, end) of the last costed neighbours.
  * mgl_debug_set: key 0 = stop the neighbour kernels after a phase (tools/phase_cost.py), 50 =
  * stage timing in the accept path; key 1 = make the parallel builder redo every chain segment
  * serially (exercises its fallback); key 2 = shrink the first-pass change lists (a multiple of 8,

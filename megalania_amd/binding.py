@@ -27,10 +27,11 @@ F_FULLWALK = 2
 F_PROFILE = 4
 F_NO_SNAPSHOTS = 8
 F_SERIAL_BUILD = 16
+ACCEPT_AUTO, ACCEPT_SINGLE, ACCEPT_BULK = 0, 1, 2
 
 HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
-    "mgl_sa_set_slab", "mgl_sa_seed_greedy", "mgl_sa_set_temperature", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
+    "mgl_sa_set_slab", "mgl_sa_seed_greedy", "mgl_sa_set_temperature", "mgl_sa_set_accept_mode", "mgl_sa_step_modes", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
     "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump", "mgl_debug_set",
 ]
 HOST_SYMBOLS = [
@@ -59,7 +60,8 @@ class Stats(C.Structure):
                 ("improved", C.c_uint64), ("current_cost", C.c_uint64), ("best_cost", C.c_uint64),
                 ("packets", C.c_uint64), ("packets_evaluated", C.c_uint64), ("gpu_ms_total", C.c_double),
                 ("gpu_ms_neighbours", C.c_double), ("gpu_ms_rebuild", C.c_double), ("neighbour_launches", C.c_uint64),
-                ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64), ("second_pass_neighbours", C.c_uint64)]
+                ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64), ("second_pass_neighbours", C.c_uint64),
+                ("bulk_steps", C.c_uint64), ("dropped_neighbours", C.c_uint64), ("improving_neighbours", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -96,6 +98,8 @@ def hip_lib():
         L.mgl_sa_seed_greedy.argtypes = [C.c_void_p, C.c_uint32]
         L.mgl_sa_set_temperature.argtypes = [C.c_void_p, C.c_uint64]
         L.mgl_sa_set_best.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mgl_sa_set_accept_mode.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        L.mgl_sa_step_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mgl_sa_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats)]
         L.mgl_sa_current.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
         L.mgl_sa_best.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
@@ -158,7 +162,7 @@ class SA:
 
     def __init__(self, data: bytes, neighbours_per_step=4096, seed=1673551, top_k=20, lc=0, lp=0, pb=0,
                  dict_limit=0, max_bucket_scan=0, iters_per_epoch=0, device=0, timing=False, fullwalk=False,
-                 snapshots=True, serial_build=False, flags=0):
+                 snapshots=True, serial_build=False, flags=0, accept=None, bulk_threshold=0):
         self.L = hip_lib()
         if self.L.mgl_device_count() < 1:
             raise MglError("no HIP device visible: the search path has no CPU implementation")
@@ -173,6 +177,21 @@ class SA:
         if not self.h:
             raise MglError(self.L.mgl_last_error().decode())
         self.nprobs = 1847 + (0x300 << (lc + lp))
+        if accept is not None:
+            self.set_accept_mode(accept, bulk_threshold)
+
+    def set_accept_mode(self, mode, bulk_threshold=0):
+        """ACCEPT_AUTO (default) / ACCEPT_SINGLE / ACCEPT_BULK, or the strings "auto" / "single" / "bulk"."""
+        mode = {"auto": ACCEPT_AUTO, "single": ACCEPT_SINGLE, "bulk": ACCEPT_BULK}.get(mode, mode)
+        self._chk(self.L.mgl_sa_set_accept_mode(self.h, mode, bulk_threshold))
+
+    def step_modes(self) -> np.ndarray:
+        """per step of the last run(): 0 single, 1 bulk"""
+        cnt = C.c_size_t(0)
+        self._chk(self.L.mgl_sa_step_modes(self.h, None, 0, C.byref(cnt)))
+        out = np.zeros(max(1, cnt.value), dtype=np.uint8)
+        self._chk(self.L.mgl_sa_step_modes(self.h, _ptr(out), cnt.value, C.byref(cnt)))
+        return out[: cnt.value]
 
     def close(self):
         if getattr(self, "h", None):

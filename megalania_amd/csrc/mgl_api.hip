@@ -5,6 +5,7 @@
 #include "mgl_kernels.hip"
 #include "mgl_kernels2.hip"
 #include "mgl_kernels3.hip"
+#include "mgl_kernels4.hip"
 #include "mgl_pbuild.hip"
 #include "mgl_index.hip"
 #include "../../include/megalania_hip.h"
@@ -20,6 +21,7 @@ static const uint16_t k_cost_table[2048] = {
 #include "mgl_cost_table.inc"
 };
 
+#define MGL_MAX_INPUT 176000000ull
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg)
 {
@@ -109,6 +111,13 @@ struct mgl_sa {
 	PBuild pb;
 	hipEvent_t ev_begin, ev_end;
 	std::vector<hipEvent_t> ev_pool;
+	/* the step's decision: single (one winner, incremental accept) or bulk (every window-best acceptable
+	 * neighbour, parallel rebuild); MGL_ACCEPT_AUTO switches between them block by block */
+	int accept_mode = MGL_ACCEPT_AUTO;
+	uint32_t bulk_threshold = 0;   /* improving neighbours per step above which a bulk step pays */
+	bool bulk_now = true;          /* AUTO: what the next block of steps runs as */
+	BulkBuf bulk;
+	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
 };
 
 static uint64_t ceil_sqrt_u64(uint64_t x)
@@ -250,6 +259,14 @@ static int rebuild_base(mgl_sa* sa, int after_accept)
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
+/* every packet on the current base's walk reproduces the input (incremental engine: needs the special-state records) */
+static int launch_validate(mgl_sa* sa)
+{
+	if (!sa->incremental) return MGL_OK;
+	hipLaunchKernelGGL(k_validate, dim3((sa->ctx.n + 255u) / 256u), dim3(256), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
 /* incremental engine, after k_decide: fold the winner into the base structures */
 static int launch_apply(mgl_sa* sa)
 {
@@ -354,7 +371,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_bucket_nx); dfree(sa->d_quad_pos); dfree(sa->d_quad_nx); dfree(sa->d_cost_tbl);
 	free_base(sa->base); free_base(sa->scratch);
 	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
-	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.dpos);
+	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.win); dfree(sa->nbr.dpos);
+	dfree(sa->bulk.ckey); dfree(sa->bulk.cwin); dfree(sa->bulk.taken); dfree(sa->bulk.hdr);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	free_b2(sa->b2, false);
@@ -458,6 +476,17 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMalloc(&sa->nbr.cost, sizeof(uint64_t) * K));
 	HIPCHK(hipMalloc(&sa->nbr.ndiffs, sizeof(uint32_t) * K));
 	HIPCHK(hipMalloc(&sa->nbr.walked, sizeof(uint32_t) * K));
+	HIPCHK(hipMalloc(&sa->nbr.win, sizeof(uint32_t) * 2 * K));
+	HIPCHK(hipMemset(sa->nbr.win, 0xFF, sizeof(uint32_t) * 2 * K));
+	memset(&sa->bulk, 0, sizeof sa->bulk);
+	HIPCHK(hipMalloc(&sa->bulk.ckey, sizeof(uint64_t) * K));
+	HIPCHK(hipMalloc(&sa->bulk.cwin, sizeof(uint2) * K));
+	HIPCHK(hipMalloc(&sa->bulk.taken, sizeof(uint32_t) * K));
+	HIPCHK(hipMalloc(&sa->bulk.hdr, sizeof(unsigned long long) * 8));
+	{
+		const unsigned long long h0[8] = { 0, 0, 0, 0, 0, 0, ~0ull, 0 };
+		HIPCHK(hipMemcpy(sa->bulk.hdr, h0, sizeof h0, hipMemcpyHostToDevice));
+	}
 	HIPCHK(hipMalloc(&sa->nbr.dpos, sizeof(uint32_t) * K * MGL_MAX_DIFFS));
 	HIPCHK(hipMalloc(&sa->nbr.dold, sizeof(mgl_pk) * K * MGL_MAX_DIFFS));
 	HIPCHK(hipMalloc(&sa->nbr.dnew, sizeof(mgl_pk) * K * MGL_MAX_DIFFS));
@@ -650,6 +679,9 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	}
 
 	sa->sqrt_thresh = ceil_sqrt_u64(sa->cfg.iters_per_epoch);
+	/* a bulk step costs a parallel rebuild (about 3 single steps at 100 KB, 6 at 10 MB, 20 at 100 MB) */
+	sa->bulk_threshold = getenv("MGL_BULK_THRESHOLD") ? (uint32_t)atoi(getenv("MGL_BULK_THRESHOLD")) : (n <= (1u << 20) ? 16u : n <= (1u << 24) ? 32u : 128u);
+	if (sa->bulk_threshold == 0) sa->bulk_threshold = 1;
 
 	/* packet_slab_new: all-literal current and best slabs */
 	hipLaunchKernelGGL(k_fill_literal, dim3(1024), dim3(256), 0, sa->stream, sa->base.v.slab, sa->ctx.n);
@@ -660,12 +692,20 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	if (rc) return rc;
 	if (sa->incremental && sa->snapshots && (rc = launch_snapshot(sa, sa->snap_lit, 0, 0, 0))) return rc;
 	HIPCHK(hipStreamSynchronize(sa->stream));
+	{
+		/* an input the structures were not sized for shows here, not steps later inside mgl_sa_run */
+		Control c0;
+		HIPCHK(hipMemcpy(&c0, sa->base.ctl, sizeof c0, hipMemcpyDeviceToHost));
+		if (c0.error_flags) return fail(MGL_EDEVICE, "mgl_sa_create: building the base structures of the all-literal slab failed");
+	}
 	return MGL_OK;
 }
 
 extern "C" mgl_sa* mgl_sa_create(const uint8_t* data, size_t n, mgl_properties props, const mgl_sa_config* cfg)
 {
-	if (!data || n == 0 || n > 0xFFFFFF00ull || !cfg) { fail(MGL_EINVAL, "mgl_sa_create: bad data/size/config"); return nullptr; }
+	if (!data || n == 0 || !cfg) { fail(MGL_EINVAL, "mgl_sa_create: bad data/size/config"); return nullptr; }
+	/* 32-bit chain pool: 24 n + 272 contexts + slack must fit (and costs stay below 2^44: k_decide packs cost << 20 | j) */
+	if (n > MGL_MAX_INPUT) { fail(MGL_EINVAL, "mgl_sa_create: input larger than 176 000 000 bytes is not supported"); return nullptr; }
 	if (props.lc + props.lp > 4 || props.pb > 4 || props.lc > 8) { fail(MGL_EINVAL, "mgl_sa_create: unsupported lc/lp/pb"); return nullptr; }
 	mgl_sa* sa = new (std::nothrow) mgl_sa();
 	if (!sa) { fail(MGL_ENOMEM, "mgl_sa_create: out of host memory"); return nullptr; }
@@ -761,8 +801,9 @@ extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
 	if ((rc = rebuild_base(sa, 0))) return rc;
+	if ((rc = launch_validate(sa))) return rc;
 	if ((rc = read_ctl(sa, sa->base, &c))) return rc;
-	if (c.error_flags) return fail(MGL_EINVAL, "mgl_sa_set_slab: slab is not a valid parse");
+	if (c.error_flags) return fail(MGL_EINVAL, "mgl_sa_set_slab: slab is not a valid parse of the input");
 	return MGL_OK;
 }
 
@@ -803,6 +844,57 @@ static hipEvent_t pool_event(mgl_sa* sa, size_t i)
 	return sa->ev_pool[i];
 }
 
+extern "C" int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_threshold)
+{
+	if (!sa) return fail(MGL_EINVAL, "null handle");
+	if (mode != MGL_ACCEPT_AUTO && mode != MGL_ACCEPT_SINGLE && mode != MGL_ACCEPT_BULK) return fail(MGL_EINVAL, "mgl_sa_set_accept_mode: unknown mode");
+	if (mode == MGL_ACCEPT_BULK && !(sa->incremental && sa->parallel_build)) return fail(MGL_EINVAL, "mgl_sa_set_accept_mode: bulk steps need the incremental engine and its parallel builder");
+	sa->accept_mode = mode;
+	if (bulk_threshold) sa->bulk_threshold = bulk_threshold;
+	sa->bulk_now = true;
+	return MGL_OK;
+}
+extern "C" int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, size_t* count)
+{
+	if (!sa || !count) return fail(MGL_EINVAL, "null argument");
+	*count = sa->mode_log.size();
+	if (modes_out) memcpy(modes_out, sa->mode_log.data(), cap < sa->mode_log.size() ? cap : sa->mode_log.size());
+	return MGL_OK;
+}
+
+static DecideArgs decide_args(const mgl_sa* sa)
+{
+	DecideArgs a;
+	a.K = sa->cfg.neighbours_per_step; a.seed = sa->cfg.seed; a.iters_per_epoch = sa->cfg.iters_per_epoch;
+	a.sqrt_thresh = sa->sqrt_thresh; a.temperature = sa->temperature;
+	return a;
+}
+/* the tail of a bulk step: selection, journals into the slab, parallel rebuild, best-slab tracking */
+static int launch_bulk_tail(mgl_sa* sa)
+{
+	const uint32_t K = sa->cfg.neighbours_per_step;
+	const DecideArgs a = decide_args(sa);
+	const uint32_t blocks = (K + 255u) / 256u;
+	hipLaunchKernelGGL(k_bulk_prep, dim3(blocks), dim3(256), 0, sa->stream, sa->ctx, sa->base.ctl, sa->nbr, a, sa->bulk);
+	hipLaunchKernelGGL(k_bulk_select, dim3(blocks), dim3(256), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, sa->base.v.slab);
+	hipLaunchKernelGGL(k_bulk_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, a);
+	HIPCHK(hipGetLastError());
+	int rc = launch_pbuild(sa);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_bulk_finish, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, sa->snapshots ? 1 : 0,
+	                   sa->snapshots ? &sa->d_snap_meta[1].valid : (uint32_t*)nullptr);
+	if (sa->snapshots) {
+		hipLaunchKernelGGL(k_bulk_keep_copy, dim3(1024), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+		hipLaunchKernelGGL(k_bulk_keep_undo, dim3(64), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->d_best);
+	} else {
+		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+	}
+	hipLaunchKernelGGL(k_bulk_reset, dim3(1), dim3(64), 0, sa->stream, sa->bulk);
+	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, 0, sa->d_counts, 0);
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
+
 extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 {
 	if (!sa) return fail(MGL_EINVAL, "null handle");
@@ -812,32 +904,57 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	if (rc) return rc;
 	const bool timing = (sa->cfg.flags & MGL_F_TIMING) != 0;
 	const uint64_t timed_steps = timing ? (steps < 512 ? steps : 512) : 0;
-	const uint32_t K = sa->cfg.neighbours_per_step;
+	const bool inc_apply = sa->incremental && sa->incremental_apply;
+	const DecideArgs dargs = decide_args(sa);
+	const int mode = (sa->incremental && sa->parallel_build) ? sa->accept_mode : MGL_ACCEPT_SINGLE; /* bulk steps rebuild with the parallel builder */
+	sa->mode_log.clear();
+	uint64_t imp_seen = before.imp_cands, last_block = 0;
 	HIPCHK(hipEventRecord(sa->ev_begin, sa->stream));
-	for (uint64_t s = 0; s < steps; s++) {
-		const bool t = s < timed_steps;
-		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
-		if ((rc = launch_neighbours(sa, ~0ull, s == 0 || !(sa->incremental && sa->incremental_apply)))) return rc;
-		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
-		const bool inc_apply = sa->incremental && sa->incremental_apply;
-		hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, K,
-		                   sa->cfg.seed, sa->cfg.iters_per_epoch, sa->sqrt_thresh, inc_apply ? 0 : 1, sa->temperature);
-		HIPCHK(hipGetLastError());
-		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
-		if (inc_apply) {
-			if ((rc = launch_apply(sa))) return rc;
-		} else {
-			hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
-			                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+	for (uint64_t s = 0; s < steps;) {
+		const bool bulk = mode == MGL_ACCEPT_BULK || (mode == MGL_ACCEPT_AUTO && sa->bulk_now);
+		/* AUTO looks at the device counters between blocks of steps (one small read-back per block) */
+		uint64_t block = steps - s;
+		if (mode == MGL_ACCEPT_AUTO) { const uint64_t b = bulk ? 4u : 16u; block = block < b ? block : b; }
+		last_block = block;
+		for (uint64_t e = s + block; s < e; s++) {
+			const bool t = s < timed_steps;
+			sa->mode_log.push_back(bulk ? 1 : 0);
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
+			if ((rc = launch_neighbours(sa, ~0ull, s == 0 || !inc_apply))) return rc;
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
+			if (bulk) {
+				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
+				if ((rc = launch_bulk_tail(sa))) return rc;
+				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
+				continue;
+			}
+			hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, dargs, inc_apply ? 0 : 1);
 			HIPCHK(hipGetLastError());
-			if ((rc = rebuild_base(sa, 1))) return rc;
-			if (sa->incremental && sa->snapshots && (rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1))) return rc;
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
+			if (inc_apply) {
+				if ((rc = launch_apply(sa))) return rc;
+			} else {
+				hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
+				                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
+				HIPCHK(hipGetLastError());
+				if ((rc = rebuild_base(sa, 1))) return rc;
+				if (sa->incremental && sa->snapshots && (rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1))) return rc;
+			}
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 		}
-		if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
+		if (mode == MGL_ACCEPT_AUTO && s < steps) {
+			Control now;
+			if ((rc = read_ctl(sa, sa->base, &now))) return rc;
+			if (now.error_flags) break;
+			sa->bulk_now = (now.imp_cands - imp_seen) >= (uint64_t)sa->bulk_threshold * block;
+			imp_seen = now.imp_cands;
+		}
 	}
 	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &after))) return rc;
+	if (mode == MGL_ACCEPT_AUTO && last_block) /* the last block decides how the next call starts */
+		sa->bulk_now = (after.imp_cands - imp_seen) >= (uint64_t)sa->bulk_threshold * last_block;
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
 		stats->steps = after.gstep - before.gstep;
@@ -862,6 +979,9 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		stats->full_rebuilds = after.full_rebuilds - before.full_rebuilds;
 		stats->fallback_neighbours = after.fallback_nbrs - before.fallback_nbrs;
 		stats->second_pass_neighbours = after.big_nbrs - before.big_nbrs;
+		stats->bulk_steps = after.bulk_steps - before.bulk_steps;
+		stats->dropped_neighbours = after.dropped - before.dropped;
+		stats->improving_neighbours = after.imp_cands - before.imp_cands;
 	}
 	if (after.error_flags) {
 		char buf[96];
@@ -1048,14 +1168,14 @@ extern "C" int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs,
 extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes)
 {
 	if (!sa || !out || !bytes) return fail(MGL_EINVAL, "null argument");
-	if (!sa->incremental) return fail(MGL_EINVAL, "mgl_debug_dump: handle runs the full-walk engine");
+	if (!sa->incremental && what != 21) return fail(MGL_EINVAL, "mgl_debug_dump: handle runs the full-walk engine");
 	HIPCHK(hipSetDevice(sa->device));
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	const Base2& b = sa->b2;
 	const void* src = nullptr;
 	size_t sz = 0;
 	uint32_t top = 0;
-	HIPCHK(hipMemcpy(&top, b.pool_top, sizeof top, hipMemcpyDeviceToHost));
+	if (sa->incremental) HIPCHK(hipMemcpy(&top, b.pool_top, sizeof top, hipMemcpyDeviceToHost));
 	switch (what) {
 	case 0: src = b.ch_off; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 1: src = b.ch_len; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
@@ -1075,6 +1195,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 19: src = sa->d_quad_nx; sz = sizeof(uint16_t) * (sa->n - 1); break;
 	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
 	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 21: src = sa->nbr.win; sz = sizeof(uint32_t) * 2 * sa->cfg.neighbours_per_step; break; /* windows of the last costed neighbours */
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");
 	}

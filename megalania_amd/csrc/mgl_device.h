@@ -79,14 +79,26 @@ struct Control {
 	uint32_t final_ctx_state;
 	uint32_t final_dists[4];
 	uint32_t error_flags;
+	/* batched decision (mgl_kernels4.hip) */
+	uint64_t imp_cands;      /* neighbours that cost less than the current slab, summed over steps */
+	uint64_t dropped;        /* neighbours dropped because their journal outgrew MGL_MAX_DIFFS */
+	uint64_t bulk_steps;     /* steps that took every window-best acceptable neighbour */
+	uint32_t taken;          /* neighbours the last step took */
+	uint32_t bulk_was_best;  /* bulk step: the base held the best slab's structures when the step began */
+	uint32_t bulk_need_undo; /* bulk step: the best slab has to be restored from the new one + the undo log */
 };
 #define MGL_ERR_REBUILD_MISMATCH 1u
 #define MGL_ERR_WALK_OVERRUN 2u
+#define MGL_ERR_BAD_PACKET 4u /* a packet that does not reproduce the input (k_validate) */
 
+#define MGL_WIN_NONE 0xFFFFFFFFu    /* no cost: no candidate at the target / handed to a later pass */
+#define MGL_WIN_DROPPED 0xFFFFFFFEu /* no cost: the journal outgrew MGL_MAX_DIFFS */
 struct NbrOut {
 	uint64_t* cost;    /* K */
 	uint32_t* ndiffs;  /* K */
 	uint32_t* walked;  /* K: packets costed by the neighbour (from its checkpoint on) */
+	uint32_t* win;     /* 2 K: target position; first position from which neighbour and base are coded
+	                    * identically again (n if never), or MGL_WIN_NONE / MGL_WIN_DROPPED with an invalid cost */
 	uint32_t* dpos;    /* K x MGL_MAX_DIFFS */
 	mgl_pk* dold;
 	mgl_pk* dnew;

@@ -7,8 +7,7 @@
  *                  nearest checkpoint, mutate (packet_slab_neighbour.c:119-152), wave-wide
  *                  top-K (top_k_packet_finder.c:95-125 over packet_enumerator.c:57-74 and
  *                  substring_enumerator.c:85-105), repair + cost to the end (:82-117)
- *   k_decide       best-of-K reduction + the accept rule of main.c:86-96, winner's journal
- *                  applied to the base slab
+ *   (k_decide and the bulk decision live in mgl_kernels4.hip)
  *   k_copy_best    main.c:91
  *   k_topk_probe / k_substrings / k_import / k_export   parity hooks and layout conversion
  *
@@ -644,6 +643,40 @@ __device__ __forceinline__ bool long_rep_ok(const DevCtx& c, const Walk& w, uint
 	return __ballot(bad) == 0;
 }
 
+/* The neighbour's packet at p: its journal entry if it has one, else the base slab's. */
+__device__ __forceinline__ mgl_pk journal_or_base(const Journal& jn, const mgl_pk* slab, uint32_t p, uint32_t lane)
+{
+	const bool hit = lane < jn.count && jn.pos[lane] == p; /* MGL_MAX_DIFFS == 64: one entry per lane */
+	const unsigned long long m = __ballot(hit);
+	if (m) return jn.neu[(uint32_t)__ffsll((long long)m) - 1u];
+	return slab[p];
+}
+/* End of the neighbour's window: the first position at which its walk and the base's stand on the
+ * same byte with the same ctx_state and rep distances, at least three repair packets after the
+ * mutated one (the incremental kernel stops its two-pointer walk there).  The
+ * full-walk engine has walked to the end of the file, so it finds the point afterwards from the
+ * journal.  `st` = walk state at the target (uniform). */
+__device__ uint32_t window_end_from_journal(const DevCtx& c, const mgl_pk* slab, const Journal& jn, mgl_wstate st, uint32_t lane)
+{
+	mgl_wstate nb = st, bs = st;
+	uint32_t count = 0;
+	bool first = true;
+	for (;;) {
+		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state && nb.dists[0] == bs.dists[0] &&
+		    nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] && nb.dists[3] == bs.dists[3]) return nb.pos;
+		if (nb.pos >= c.n && bs.pos >= c.n) return c.n;
+		if (nb.pos <= bs.pos && nb.pos < c.n) {
+			if (!first && count < 8) count++;
+			first = false;
+			const mgl_pk pk = uni64(journal_or_base(jn, slab, nb.pos, lane));
+			mgl_advance(&nb, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk));
+		} else {
+			const mgl_pk pk = uni64(slab[bs.pos]);
+			mgl_advance(&bs, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk));
+		}
+	}
+}
+
 /* One wavefront = one neighbour of the base slab (packet_slab_neighbour.c:154-173). */
 /* todo != nullptr: only the neighbours listed there are evaluated (the ones the incremental
  * kernel could not fit), walking from byte 0 instead of from a prefix checkpoint. */
@@ -716,9 +749,10 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 		walk_packet<true>(w, c, probs, T, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), lane);
 	}
 	if (w.st.pos != target) { /* cannot happen for an on-walk target; fail safe */
-		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_NONE; }
 		return;
 	}
+	const mgl_wstate st_target = w.st;
 
 	/* mutate, packet_slab_neighbour.c:119-152 */
 	const uint32_t pos = target;
@@ -749,7 +783,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 	if (!mutated) {
 		mgl_pk picked;
 		if (!pick_from_top_k(c, w, probs, T, lencost, first, false, rng, lane, &picked)) {
-			if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+			if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_NONE; }
 			return;
 		}
 		m_first = picked;
@@ -796,9 +830,10 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 	const uint64_t total = base_cum + wave_sum64(w.acc);
 	wave_sync();
 	if (jn.overflow) {
-		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; }
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
 		return;
 	}
+	const uint32_t wend = window_end_from_journal(c, b.slab, jn, st_target, lane);
 	/* journal out: entries whose final value equals the base value are dropped */
 	uint32_t nd = 0;
 	for (uint32_t i = 0; i < jn.count; i++) {
@@ -810,97 +845,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 		}
 		nd++;
 	}
-	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = w.packets - first_packet; }
-}
-
-/* ================================================================== k_decide */
-/* Best-of-K + the accept rule of main.c:86-96, then the winner's
- * journal is applied to the base slab.  One block. */
-__global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, uint32_t K, uint64_t seed,
-                                                 uint64_t iters_per_epoch, uint64_t sqrt_thresh, int apply_journal, uint64_t temperature)
-{
-	__shared__ uint64_t s_key[16];
-	__shared__ uint64_t s_cnt[16 * 2];
-	__shared__ uint32_t s_winner;
-	const uint32_t tid = threadIdx.x;
-	uint64_t best = MGL_INVALID_COST, valid = 0, walked = 0;
-	for (uint32_t j = tid; j < K; j += blockDim.x) {
-		const uint64_t cst = out.cost[j];
-		const uint64_t wk = out.walked[j]; /* both loads in flight together */
-		if (cst != MGL_INVALID_COST) {
-			valid++; walked += wk;
-			const uint64_t key = (cst << 20) | j;
-			best = key < best ? key : best;
-		}
-	}
-	/* per wavefront through lane exchanges, then one value per wavefront through LDS */
-	for (int o = 32; o > 0; o >>= 1) {
-		const uint64_t ob = (uint64_t)__shfl_xor((unsigned long long)best, o, 64);
-		best = ob < best ? ob : best;
-		valid += (uint64_t)__shfl_xor((unsigned long long)valid, o, 64);
-		walked += (uint64_t)__shfl_xor((unsigned long long)walked, o, 64);
-	}
-	if ((tid & 63u) == 0) { s_key[tid >> 6] = best; s_cnt[tid >> 6] = valid; s_cnt[16 + (tid >> 6)] = walked; }
-	__syncthreads();
-	if (tid == 0) {
-		for (uint32_t w = 1; w < (blockDim.x >> 6); w++) {
-			s_key[0] = s_key[w] < s_key[0] ? s_key[w] : s_key[0];
-			s_cnt[0] += s_cnt[w];
-			s_cnt[16] += s_cnt[16 + w];
-		}
-	}
-	if (tid == 0) {
-		const uint64_t gstep = ctl->gstep, i = ctl->iter;
-		const uint64_t bkey = s_key[0];
-		uint32_t winner = ~0u;
-		if (bkey != MGL_INVALID_COST) {
-			const uint64_t bcost = bkey >> 20;
-			const uint64_t key = mgl_rng_key(seed, gstep, 0xFFFFFFFFu);
-			const uint64_t m = i * i + 1 + (uint64_t)ctl->phase * iters_per_epoch / 2;
-			const bool transition = ((uint64_t)mgl_rng_draw(key, 0) % m) < sqrt_thresh;
-			if (ctl->cur_cost == 0 || bcost < ctl->cur_cost) winner = (uint32_t)(bkey & 0xFFFFFu);
-			else if (temperature) {
-				/* opt-in Metropolis rule (not in the reference; mgl_sa_set_temperature): the random
-				 * neighbour is taken iff u < exp(-delta / t), through the cost table: T[u] = -log2(u / 2048) * 2048 */
-				const uint32_t jr = mgl_rng_draw(key, 1) % K;
-				const uint64_t cj = out.cost[jr];
-				if (cj != MGL_INVALID_COST) {
-					const uint32_t u = mgl_rng_draw(key, 0) % 2047u + 1u;
-					const uint64_t ic = i < iters_per_epoch ? i : iters_per_epoch;
-					const uint64_t t_eff = temperature * (iters_per_epoch - ic) / iters_per_epoch;
-					const uint64_t delta = cj - ctl->cur_cost;
-					if (delta * 2048u <= t_eff * (uint64_t)c.cost_tbl[u]) winner = jr;
-				}
-			} else if (transition) {
-				const uint32_t jr = mgl_rng_draw(key, 1) % K;
-				if (out.cost[jr] != MGL_INVALID_COST) winner = jr;
-			}
-		}
-		ctl->evals += s_cnt[0];
-		ctl->failed += K - s_cnt[0];
-		ctl->packets_eval += s_cnt[16];
-		ctl->gstep = gstep + 1;
-		ctl->iter = i + 1;
-		ctl->winner = winner;
-		ctl->accepted_flag = winner != ~0u;
-		ctl->copy_best_flag = 0;
-		if (winner != ~0u) {
-			ctl->accepted++;
-			ctl->cur_cost = out.cost[winner];
-			ctl->dirty_pos = out.dpos[(size_t)winner * MGL_MAX_DIFFS];
-			if (ctl->best_cost == 0 || ctl->cur_cost < ctl->best_cost) {
-				ctl->best_cost = ctl->cur_cost;
-				ctl->copy_best_flag = 1;
-				ctl->improved++;
-			}
-		}
-		s_winner = winner;
-	}
-	__syncthreads();
-	const uint32_t winner = s_winner;
-	if (winner == ~0u || !apply_journal) return; /* incremental engine: k_apply_walk writes the journal */
-	const uint32_t nd = out.ndiffs[winner];
-	if (tid < nd) b.slab[out.dpos[(size_t)winner * MGL_MAX_DIFFS + tid]] = out.dnew[(size_t)winner * MGL_MAX_DIFFS + tid];
+	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = wend; }
 }
 
 /* main.c:91 -- the new best slab (after the journal has been applied) */

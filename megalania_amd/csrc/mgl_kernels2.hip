@@ -823,6 +823,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	bool generate_failed = false, sim_deferred = false;
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
+	uint32_t wend = 0; /* where the two walks meet again: the end of this neighbour's window */
 	bool first_packet = true;
 	uint32_t guard = 0;
 	/* the second pass, too, takes the mutation's pick from the first half when there was one */
@@ -1030,6 +1031,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 			prof_mark(prof, 3, lane); /* window walk */
 			if (c.diag_stop == 4) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = ch.n_ins + ch.n_rem; } return; }
 			if (ch.overflow || jn.overflow || too_many) { phase = P_OUT; continue; }
+			wend = nb.pos;
 			sim_limit = MGL_POS_INF; sim_overlay = false; phase = P_SIM;
 			continue;
 		}
@@ -1037,11 +1039,11 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	}
 
 	if (generate_failed) { /* no candidate at the target (main.c:81-84 retries those) */
-		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; }
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_NONE; }
 		return;
 	}
 	if (jn.overflow) { /* same rule as the full-walk path and the oracle: dropped */
-		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; }
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
 		return;
 	}
 	if (ch.overflow || too_many) {
@@ -1050,7 +1052,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 			const uint32_t slot2 = atomicAdd(todo_count, 1u);
 			todo[slot2] = j;
 			atomicAdd((unsigned long long*)(BIG ? &ctl->fallback_nbrs : &ctl->big_nbrs), 1ull);
-			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
+			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_NONE;
 		}
 		return;
 	}
@@ -1065,7 +1067,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 		}
 		nd++;
 	}
-	if (lane == 0) { if (!sim_deferred) out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; }
+	if (lane == 0) { if (!sim_deferred) out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; out.win[2u * j] = pos; out.win[2u * j + 1u] = wend; }
 	if (prof_acc && lane == 0) /* diagnostic: wave lifetime (40 bits) | change events (12 bits) | packets walked (12 bits) */
 		prof_acc[32 + j] = ((__builtin_readcyclecounter() - t_begin) & 0xFFFFFFFFFFull) |
 		                   ((unsigned long long)((ch.n_ins + ch.n_rem) & 0xFFFu) << 40) | ((unsigned long long)(walked & 0xFFFu) << 52);
@@ -1128,7 +1130,7 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b
 			const uint32_t slot2 = atomicAdd(todo_count, 1u);
 			todo[slot2] = j;
 			atomicAdd((unsigned long long*)&ctl->big_nbrs, 1ull);
-			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0;
+			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j + 1u] = MGL_WIN_NONE;
 		}
 		return;
 	}

@@ -801,3 +801,39 @@ __global__ void __launch_bounds__(256) k_apply_jobs(Base2 b, const Control* ctl,
 		for (uint32_t i = threadIdx.x; i < job.z; i += blockDim.x) { dp[i] = sp[i]; de[i] = se[i]; }
 	}
 }
+
+/* ================================================================== slab validation
+ *
+ * The reference emits whatever slab it is given (main.c:116-118).  A slab that enters from outside
+ * (mgl_sa_set_slab, mgl_sa_adopt_best / mgl_sa_set_best) is checked here, after its base structures
+ * exist: one thread per on-walk position; the walk state before every non-literal packet is its
+ * special-state record.  Any violation raises MGL_ERR_BAD_PACKET. */
+__global__ void __launch_bounds__(256) k_validate(DevCtx c, Base2 b, Control* ctl)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= c.n) return;
+	if (!((b.onwalk[p >> 6] >> (p & 63u)) & 1ull)) return;
+	const mgl_pk pk = b.slab[p];
+	const uint32_t type = mgl_pk_type(pk), len = mgl_pk_len(pk), dist = mgl_pk_dist(pk);
+	bool bad = type < MGL_LITERAL || type > MGL_LONG_REP || len == 0 || p + len > c.n;
+	if (!bad) {
+		if (type == MGL_LITERAL) bad = len != 1;
+		else {
+			const uint32_t* r = b.sp_state + (size_t)p * 8;
+			const uint32_t d0 = r[1], d1 = r[2], d2 = r[3], d3 = r[4];
+			uint32_t src = 0;
+			if (type == MGL_SHORT_REP) { bad = len != 1; src = d0; }
+			else {
+				bad = len < MGL_MIN_MATCH || len > MGL_MAX_MATCH || (type == MGL_LONG_REP && dist > 3u);
+				src = type == MGL_MATCH ? dist : (dist == 0 ? d0 : dist == 1 ? d1 : dist == 2 ? d2 : d3);
+			}
+			if (!bad) bad = src >= p || src >= c.dict_limit;
+			if (!bad) {
+				const uint8_t* a = c.data + p - src - 1u;
+				const uint8_t* z = c.data + p;
+				for (uint32_t i = 0; i < len; i++) if (a[i] != z[i]) { bad = true; break; }
+			}
+		}
+	}
+	if (bad) atomicOr(&ctl->error_flags, MGL_ERR_BAD_PACKET);
+}

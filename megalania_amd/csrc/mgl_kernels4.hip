@@ -1,0 +1,281 @@
+/*
+ * mgl_kernels4.hip -- the step's decision: which of the K costed neighbours
+ * the chain moves to.
+ *
+ * Every evaluation keeps the reference's own rule (main.c:86-87): neighbour j of a step is the
+ * epoch's iteration i = Control::iter + j and is *acceptable* when it costs less than the current
+ * slab or when its transition draw  draw % (i*i + 1 + phase*N/2) < sqrt(N)  says so (opt-in, not in the
+ * reference: with a temperature, when u < exp(-delta / t_eff) instead, in integers through the
+ * reference's log table).  Acceptable neighbours are ranked by key = (improving ? 0 : 1, cost, j).
+ *
+ *   k_decide        single mode: the acceptable neighbour with the smallest key wins; the accept
+ *                   path (mgl_kernels3.hip) folds it into the base structures incrementally.
+ *   k_bulk_prep / k_bulk_select / k_bulk_end / k_bulk_finish / k_bulk_keep_*
+ *                   bulk mode: every acceptable neighbour whose window [target, end) overlaps no
+ *                   acceptable neighbour of smaller key is taken in the same step.  Windows are
+ *                   where a neighbour's walk differs from the base's, so disjoint windows give a
+ *                   valid parse; the journals go into the slab, the base structures are re-derived
+ *                   by the parallel builder (mgl_pbuild.hip), and the new total is its exact cost.
+ *
+ * Both are mirrored by oracle/mgl_oracle.c:orc_sa_batched, step by step, bit for bit.
+ */
+#include "mgl_device.h"
+
+struct DecideArgs {
+	uint32_t K;
+	uint64_t seed;
+	uint64_t iters_per_epoch;
+	uint64_t sqrt_thresh;
+	uint64_t temperature;
+};
+
+/* one neighbour's verdict; key = ~0 when it is not acceptable */
+struct Verdict {
+	uint64_t key;
+	uint32_t valid, improving, dropped, walked;
+};
+__device__ __forceinline__ Verdict judge(const DevCtx& c, const Control* ctl, const NbrOut& out, const DecideArgs& a, uint32_t j,
+                                         uint64_t base_cost, uint64_t gstep, uint64_t iter)
+{
+	Verdict v;
+	v.key = MGL_INVALID_COST; v.valid = 0; v.improving = 0; v.dropped = 0; v.walked = 0;
+	const uint64_t cst = out.cost[j];
+	const uint32_t wk = out.walked[j], we = out.win[2u * j + 1u];
+	if (cst == MGL_INVALID_COST) { v.dropped = we == MGL_WIN_DROPPED ? 1u : 0u; return v; }
+	v.valid = 1; v.walked = wk;
+	bool ok = cst < base_cost;
+	v.improving = ok ? 1u : 0u;
+	if (!ok) {
+		uint64_t i = iter + j;
+		if (i > 0x7FFFFFFFull) i = 0x7FFFFFFFull;
+		const uint32_t draw = mgl_rng_draw(mgl_rng_key(a.seed, gstep, 0xFFFFFFFFu), 2u + j);
+		if (a.temperature) {
+			const uint32_t u = draw % 2047u + 1u;
+			const uint64_t ic = i < a.iters_per_epoch ? i : a.iters_per_epoch;
+			const uint64_t t_eff = a.temperature * (a.iters_per_epoch - ic) / a.iters_per_epoch;
+			ok = (cst - base_cost) * 2048u <= t_eff * (uint64_t)c.cost_tbl[u];
+		} else {
+			const uint64_t m = i * i + 1ull + (uint64_t)ctl->phase * a.iters_per_epoch / 2ull;
+			ok = ((uint64_t)draw % m) < a.sqrt_thresh;
+		}
+	}
+	if (ok) v.key = ((v.improving ? 0ull : 1ull) << 63) | (cst << 20) | j;
+	return v;
+}
+
+/* ================================================================== k_decide (single mode) */
+__global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* ctl, NbrOut out, DecideArgs a, int apply_journal)
+{
+	__shared__ uint64_t s_key[16];
+	__shared__ uint64_t s_cnt[16 * 4];
+	__shared__ uint32_t s_winner;
+	const uint32_t tid = threadIdx.x;
+	const uint64_t gstep = ctl->gstep, iter = ctl->iter;
+	const uint64_t base_cost = ctl->cur_cost ? ctl->cur_cost : ctl->rebuild_cost;
+	uint64_t best = MGL_INVALID_COST, valid = 0, walked = 0, imp = 0, dropped = 0;
+	for (uint32_t j = tid; j < a.K; j += blockDim.x) {
+		const Verdict v = judge(c, ctl, out, a, j, base_cost, gstep, iter);
+		valid += v.valid; walked += v.walked; imp += v.improving; dropped += v.dropped;
+		best = v.key < best ? v.key : best;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint64_t ob = (uint64_t)__shfl_xor((unsigned long long)best, o, 64);
+		best = ob < best ? ob : best;
+		valid += (uint64_t)__shfl_xor((unsigned long long)valid, o, 64);
+		walked += (uint64_t)__shfl_xor((unsigned long long)walked, o, 64);
+		imp += (uint64_t)__shfl_xor((unsigned long long)imp, o, 64);
+		dropped += (uint64_t)__shfl_xor((unsigned long long)dropped, o, 64);
+	}
+	if ((tid & 63u) == 0) {
+		s_key[tid >> 6] = best;
+		s_cnt[tid >> 6] = valid; s_cnt[16 + (tid >> 6)] = walked; s_cnt[32 + (tid >> 6)] = imp; s_cnt[48 + (tid >> 6)] = dropped;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		for (uint32_t w = 1; w < (blockDim.x >> 6); w++) {
+			s_key[0] = s_key[w] < s_key[0] ? s_key[w] : s_key[0];
+			s_cnt[0] += s_cnt[w]; s_cnt[16] += s_cnt[16 + w]; s_cnt[32] += s_cnt[32 + w]; s_cnt[48] += s_cnt[48 + w];
+		}
+		const uint64_t bkey = s_key[0];
+		const uint32_t winner = bkey == MGL_INVALID_COST ? ~0u : (uint32_t)(bkey & 0xFFFFFu);
+		ctl->evals += s_cnt[0];
+		ctl->failed += a.K - s_cnt[0];
+		ctl->packets_eval += s_cnt[16];
+		ctl->imp_cands += s_cnt[32];
+		ctl->dropped += s_cnt[48];
+		ctl->gstep = gstep + 1;
+		ctl->iter = iter + a.K; /* the reference's i counts evaluations (main.c:78) */
+		ctl->winner = winner;
+		ctl->accepted_flag = winner != ~0u;
+		ctl->copy_best_flag = 0;
+		ctl->taken = winner != ~0u ? 1u : 0u;
+		ctl->cur_cost = base_cost; /* an epoch's current cost starts as the exact cost of its first slab */
+		if (winner != ~0u) {
+			ctl->accepted++;
+			ctl->cur_cost = out.cost[winner];
+			ctl->dirty_pos = out.dpos[(size_t)winner * MGL_MAX_DIFFS];
+			if (ctl->best_cost == 0 || ctl->cur_cost < ctl->best_cost) {
+				ctl->best_cost = ctl->cur_cost;
+				ctl->copy_best_flag = 1;
+				ctl->improved++;
+			}
+		}
+		s_winner = winner;
+	}
+	__syncthreads();
+	const uint32_t winner = s_winner;
+	if (winner == ~0u || !apply_journal) return; /* incremental engine: k_apply_walk writes the journal */
+	const uint32_t nd = out.ndiffs[winner];
+	if (tid < nd) b.slab[out.dpos[(size_t)winner * MGL_MAX_DIFFS + tid]] = out.dnew[(size_t)winner * MGL_MAX_DIFFS + tid];
+}
+
+/* ================================================================== bulk mode */
+struct BulkBuf {
+	uint64_t* ckey;     /* K: keys of the acceptable neighbours (compacted, any order) */
+	uint2* cwin;        /* K: their windows */
+	uint32_t* taken;    /* K: neighbour indices taken this step */
+	unsigned long long* hdr; /* [0] acceptable [1] taken [2] valid [3] walked [4] improving [5] dropped [6] smallest taken key */
+};
+
+__global__ void __launch_bounds__(256) k_bulk_prep(DevCtx c, Control* ctl, NbrOut out, DecideArgs a, BulkBuf bb)
+{
+	__shared__ unsigned long long s_cnt[4];
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+	if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t base_cost = ctl->cur_cost ? ctl->cur_cost : ctl->rebuild_cost;
+	Verdict v;
+	v.key = MGL_INVALID_COST; v.valid = v.improving = v.dropped = v.walked = 0;
+	if (j < a.K) v = judge(c, ctl, out, a, j, base_cost, ctl->gstep, ctl->iter);
+	uint64_t valid = v.valid, walked = v.walked, imp = v.improving, dropped = v.dropped;
+	for (int o = 32; o > 0; o >>= 1) {
+		valid += (uint64_t)__shfl_xor((unsigned long long)valid, o, 64);
+		walked += (uint64_t)__shfl_xor((unsigned long long)walked, o, 64);
+		imp += (uint64_t)__shfl_xor((unsigned long long)imp, o, 64);
+		dropped += (uint64_t)__shfl_xor((unsigned long long)dropped, o, 64);
+	}
+	if (lane == 0) { atomicAdd(&s_cnt[0], valid); atomicAdd(&s_cnt[1], walked); atomicAdd(&s_cnt[2], imp); atomicAdd(&s_cnt[3], dropped); }
+	/* compact the acceptable ones: one atomic per wavefront */
+	const bool acc = v.key != MGL_INVALID_COST;
+	const unsigned long long m = __ballot(acc);
+	if (m) {
+		unsigned long long base = 0;
+		if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&bb.hdr[0], (unsigned long long)__popcll(m));
+		base = (unsigned long long)shfl64(base, __ffsll((long long)m) - 1);
+		if (acc) {
+			const uint32_t at = (uint32_t)base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			bb.ckey[at] = v.key;
+			bb.cwin[at] = make_uint2(out.win[2u * j], out.win[2u * j + 1u]);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd(&bb.hdr[2], s_cnt[0]); atomicAdd(&bb.hdr[3], s_cnt[1]); atomicAdd(&bb.hdr[4], s_cnt[2]); atomicAdd(&bb.hdr[5], s_cnt[3]);
+	}
+}
+
+/* a candidate is taken iff no candidate of smaller key overlaps its window; the taken ones write their
+ * journals into the slab (their windows are pairwise disjoint, so no two of them touch one entry) */
+__global__ void __launch_bounds__(256) k_bulk_select(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab)
+{
+	__shared__ uint64_t s_key[256];
+	__shared__ uint2 s_win[256];
+	const uint32_t n = (uint32_t)bb.hdr[0];
+	if (blockIdx.x * blockDim.x >= n) return;
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool mine = a < n;
+	const uint64_t key = mine ? bb.ckey[a] : 0ull;
+	const uint2 w = mine ? bb.cwin[a] : make_uint2(0u, 0u);
+	bool lose = false;
+	for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
+		__syncthreads();
+		if (t0 + threadIdx.x < n) { s_key[threadIdx.x] = bb.ckey[t0 + threadIdx.x]; s_win[threadIdx.x] = bb.cwin[t0 + threadIdx.x]; }
+		__syncthreads();
+		const uint32_t cnt = (n - t0) < 256u ? (n - t0) : 256u;
+		if (mine && !lose)
+			for (uint32_t i = 0; i < cnt; i++)
+				lose = lose || (s_key[i] < key && s_win[i].x < w.y && w.x < s_win[i].y);
+	}
+	if (!mine || lose) return;
+	const uint32_t j = (uint32_t)(key & 0xFFFFFu);
+	const unsigned long long at = atomicAdd(&bb.hdr[1], 1ull);
+	bb.taken[at] = j;
+	atomicMin(&bb.hdr[6], (unsigned long long)key);
+	const uint32_t nd = out.ndiffs[j];
+	for (uint32_t e = 0; e < nd; e++) slab[out.dpos[(size_t)j * MGL_MAX_DIFFS + e]] = out.dnew[(size_t)j * MGL_MAX_DIFFS + e];
+	(void)ctl;
+}
+
+/* bookkeeping between the selection and the rebuild */
+__global__ void k_bulk_end(Control* ctl, BulkBuf bb, DecideArgs a)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	const uint64_t base_cost = ctl->cur_cost ? ctl->cur_cost : ctl->rebuild_cost;
+	const uint32_t taken = (uint32_t)bb.hdr[1];
+	ctl->evals += bb.hdr[2];
+	ctl->failed += a.K - bb.hdr[2];
+	ctl->packets_eval += bb.hdr[3];
+	ctl->imp_cands += bb.hdr[4];
+	ctl->dropped += bb.hdr[5];
+	ctl->gstep += 1;
+	ctl->iter += a.K;
+	ctl->accepted += taken;
+	ctl->taken = taken;
+	ctl->bulk_steps += 1;
+	ctl->cur_cost = base_cost;
+	ctl->winner = ~0u;
+	ctl->accepted_flag = 0; ctl->copy_best_flag = 0; ctl->apply_failed = 0;
+	ctl->bulk_was_best = ctl->best_is_current;
+	ctl->bulk_need_undo = 0;
+}
+
+/* after the parallel builder: the new slab's exact cost is the current cost; best-slab tracking
+ * (main.c:88-92).  lazy_best: the best slab's structures live in the base while best_is_current;
+ * when a bulk step leaves the best slab (rare: it took moves and their sum did not improve) the
+ * best slab itself is restored from the new one and the undo log (k_bulk_keep_*), and its
+ * structures are re-derived when an epoch next starts from it. */
+__global__ void k_bulk_finish(Control* ctl, BulkBuf bb, int lazy_best, uint32_t* snap_best_valid)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	const uint32_t taken = ctl->taken;
+	if (taken) {
+		ctl->cur_cost = ctl->rebuild_cost;
+		if (ctl->best_cost == 0 || ctl->cur_cost < ctl->best_cost) {
+			ctl->best_cost = ctl->cur_cost;
+			ctl->copy_best_flag = 1;
+			ctl->improved++;
+		}
+		if (lazy_best) {
+			if (ctl->copy_best_flag) ctl->best_is_current = 1;
+			else if (ctl->bulk_was_best) {
+				ctl->best_is_current = 0;
+				ctl->bulk_need_undo = 1;
+				if (snap_best_valid) *snap_best_valid = 0u; /* SnapMeta::valid of the best snapshot */
+			}
+		}
+	}
+	ctl->t_last = 0; /* a bulk step is not a sample for the split / one-kernel choice */
+	bb.hdr[0] = 0; bb.hdr[1] = taken; /* k_bulk_keep_undo still needs the count; cleared there */
+	bb.hdr[2] = bb.hdr[3] = bb.hdr[4] = bb.hdr[5] = 0; bb.hdr[6] = ~0ull;
+}
+/* best slab := the slab before this step = the new slab ... */
+__global__ void __launch_bounds__(256) k_bulk_keep_copy(const Control* ctl, const mgl_pk* slab, mgl_pk* best, uint32_t n)
+{
+	if (!ctl->bulk_need_undo) return;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) best[i] = slab[i];
+}
+/* ... with the taken journals undone */
+__global__ void __launch_bounds__(256) k_bulk_keep_undo(const Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* best)
+{
+	const uint32_t taken = (uint32_t)bb.hdr[1];
+	if (ctl->bulk_need_undo) {
+		for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < taken; t += gridDim.x * blockDim.x) {
+			const uint32_t j = bb.taken[t], nd = out.ndiffs[j];
+			for (uint32_t e = 0; e < nd; e++) best[out.dpos[(size_t)j * MGL_MAX_DIFFS + e]] = out.dold[(size_t)j * MGL_MAX_DIFFS + e];
+		}
+	}
+}
+__global__ void k_bulk_reset(BulkBuf bb)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) bb.hdr[1] = 0;
+}

@@ -27,14 +27,17 @@ static void usage(const char* argv0)
 	fprintf(stderr,
 	        "usage: %s [--neighbours K] [--epochs E] [--phases P] [--steps S] [--seed N]\n"
 	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M]\n"
-	        "          [-o out.lzma] [--save-slab file] [--load-slab file] [--greedy-seed C] [--temperature B] filename\n"
+	        "          [-o out.lzma] [--save-slab file] [--load-slab file] [--greedy-seed C] [--temperature B]\n"
+	        "          [--accept auto|single|bulk] filename\n"
 	        "  -o           write the stream to a file instead of stdout\n"
 	        "  --save-slab  after every epoch, write the best packet slab (resumable checkpoint)\n"
 	        "  --load-slab  start from a slab written by --save-slab (same input, same lc/lp/pb)\n"
 	        "  --greedy-seed C  epochs that the reference starts from the all-literal slab start from a greedy\n"
 	        "               parse instead (longest of the C nearest candidates per position; e.g. 256)\n"
 	        "  --temperature B  Metropolis accept rule instead of the reference's: B = e-folding slack in output\n"
-	        "               bytes at the start of an epoch, cooled linearly to 0 (e.g. 2; 0 = reference rule)\n", argv0);
+	        "               bytes at the start of an epoch, cooled linearly to 0 (e.g. 2; 0 = reference rule)\n"
+	        "  --accept     what a step of K neighbours takes: the best acceptable one (single), every one that is\n"
+	        "               the best of its own window (bulk), or whichever pays (auto, default)\n", argv0);
 }
 
 int main(int argc, char** argv)
@@ -51,6 +54,7 @@ int main(int argc, char** argv)
 	const char *out_path = NULL, *save_path = NULL, *load_path = NULL;
 	uint32_t greedy = 0;
 	double temperature_bytes = 0;
+	int accept_mode = MGL_ACCEPT_AUTO;
 	for (int i = 1; i < argc; i++) {
 		const char* a = argv[i];
 		const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -71,6 +75,12 @@ int main(int argc, char** argv)
 		else if (!strcmp(a, "--load-slab")) load_path = v;
 		else if (!strcmp(a, "--greedy-seed")) greedy = (uint32_t)strtoul(v, NULL, 0);
 		else if (!strcmp(a, "--temperature")) temperature_bytes = strtod(v, NULL);
+		else if (!strcmp(a, "--accept")) {
+			if (!strcmp(v, "auto")) accept_mode = MGL_ACCEPT_AUTO;
+			else if (!strcmp(v, "single")) accept_mode = MGL_ACCEPT_SINGLE;
+			else if (!strcmp(v, "bulk")) accept_mode = MGL_ACCEPT_BULK;
+			else { usage(argv[0]); return -1; }
+		}
 		else { usage(argv[0]); return -1; }
 		i++;
 	}
@@ -97,6 +107,7 @@ int main(int argc, char** argv)
 		fprintf(stderr, "Error: %s\n", mgl_last_error());
 		return -1;
 	}
+	if (mgl_sa_set_accept_mode(sa, accept_mode, 0) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
 	if (packets_best == NULL) { fprintf(stderr, "Error: out of memory\n"); return -1; }
 	bool resumed = false;

@@ -229,16 +229,45 @@ bool mgl_emit_stream(const uint8_t* data, size_t n, mgl_properties props, const 
 {
 	mgl_lzma_state st;
 	if (!mgl_lzma_state_init(&st, data, n, props)) return false;
-	/* the emitter does not validate packets (neither does the reference): refuse slabs whose
-	 * walk leaves the buffer instead of reading out of bounds */
-	for (size_t pos = 0; pos < n;) {
-		const mgl_packet* p = &slab[pos];
-		if (p->type < MGL_LITERAL || p->type > MGL_LONG_REP || p->len == 0 || pos + p->len > n) {
-			fprintf(stderr, "Error: slab entry at %zu is not a packet\n", pos);
-			mgl_lzma_state_free(&st);
-			return false;
+	/* the reference's emitter codes whatever it is given (main.c:116-118) and reads
+	 * data[pos - dists[0] - 1] unguarded; here a slab is refused unless its walk is a valid parse of
+	 * the input that the header's 4 MiB dictionary can decode: packet types and lengths, MATCH
+	 * distances inside the window and the prefix, LONG_REP indices, and the copied bytes themselves */
+	{
+		mgl_wstate w;
+		memset(&w, 0, sizeof w);
+		const char* why = NULL;
+		while (w.pos < n && !why) {
+			const mgl_packet* p = &slab[w.pos];
+			const size_t pos = w.pos;
+			uint32_t src_dist = 0;
+			if (p->type < MGL_LITERAL || p->type > MGL_LONG_REP || p->len == 0 || pos + p->len > n) why = "not a packet";
+			else if (p->type == MGL_LITERAL) { if (p->len != 1) why = "literal longer than one byte"; }
+			else if (p->type == MGL_SHORT_REP) {
+				if (p->len != 1) why = "short rep longer than one byte";
+				else if (w.dists[0] >= pos || data[pos] != data[pos - w.dists[0] - 1]) why = "short rep does not reproduce the input";
+			} else {
+				if (p->len < MGL_MIN_MATCH || p->len > MGL_MAX_MATCH) why = "match length outside 2..273";
+				else if (p->type == MGL_LONG_REP && p->dist > 3) why = "rep index above 3";
+				else {
+					src_dist = p->type == MGL_MATCH ? p->dist : mgl_dist_at(&w, p->dist);
+					if (src_dist >= pos) why = "distance reaches before the start of the input";
+					else if (src_dist >= 0x400000u) why = "distance outside the 4 MiB dictionary of the header";
+					else {
+						/* overlapping copies are legal: compare byte by byte */
+						const uint8_t* a = data + pos - src_dist - 1;
+						const uint8_t* b = data + pos;
+						for (uint32_t i = 0; i < p->len; i++) if (a[i] != b[i]) { why = "match does not reproduce the input"; break; }
+					}
+				}
+			}
+			if (why) {
+				fprintf(stderr, "Error: slab entry at %zu: %s\n", pos, why);
+				mgl_lzma_state_free(&st);
+				return false;
+			}
+			mgl_advance(&w, p->type, p->dist, p->len);
 		}
-		pos += p->len;
 	}
 	mgl_lzma_encode_header(&st, output);
 	EncoderInterface enc;

@@ -75,9 +75,11 @@ struct orc_ctx {
 	uint32_t* bucket_off; /* 65536+1 */
 	uint32_t* bucket_pos; /* n-1 positions, ascending inside a bucket */
 	uint64_t temperature; /* 0 = the reference's accept rule; else the opt-in Metropolis rule of orc_sa_batched */
+	uint32_t max_bucket_scan; /* 0 = every hit (the reference); else only the nearest M hits of the window */
 };
 
 void orc_set_temperature(orc_ctx* c, uint64_t temperature) { c->temperature = temperature; }
+void orc_set_max_bucket_scan(orc_ctx* c, uint32_t m) { c->max_bucket_scan = m; }
 
 size_t orc_num_probs(const orc_ctx* c) { return c->L.total; }
 
@@ -396,16 +398,21 @@ size_t orc_trace_events(orc_ctx* c, const orc_packet* slab, uint32_t* ev_ctx, ui
 /* ---------------------------------------------------------------- enumeration */
 typedef void (*cand_cb)(void* ud, orc_packet pk, uint64_t seq);
 
-/* ref: substring_enumerator.c:85-105 (+ the dictionary window its :97 todo asks for). */
+/* ref: substring_enumerator.c:85-105 (+ the dictionary window its :97 todo asks for, and the
+ * optional fan-out cap of mgl_sa_config.max_bucket_scan: of the hits inside the window only the
+ * nearest M -- the last M of the bucket before pos -- are enumerated; the reference scans them all). */
 static void for_each_substring(const orc_ctx* c, size_t pos, size_t max_len,
                                void (*cb)(void*, size_t, size_t), void* ud)
 {
 	if (pos == 0 || pos == c->n - 1) return;
 	unsigned b = ((unsigned)c->data[pos] << 8) | c->data[pos + 1];
-	for (uint32_t i = c->bucket_off[b]; i < c->bucket_off[b + 1]; i++) {
+	uint32_t lo = c->bucket_off[b], hi = lo;
+	const uint32_t end = c->bucket_off[b + 1];
+	while (hi < end && c->bucket_pos[hi] < pos) hi++;
+	while (lo < hi && pos - c->bucket_pos[lo] - 1 >= c->dict_limit) lo++;
+	if (c->max_bucket_scan && hi - lo > c->max_bucket_scan) lo = hi - c->max_bucket_scan;
+	for (uint32_t i = lo; i < hi; i++) {
 		size_t q = c->bucket_pos[i];
-		if (q >= pos) break;
-		if (pos - q - 1 >= c->dict_limit) continue;
 		cb(ud, q, 2);
 		for (size_t j = 2; j < max_len && j + pos < c->n; j++) {
 			if (c->data[pos + j] != c->data[q + j]) break;
@@ -823,8 +830,60 @@ static int diff_cmp(const void* a, const void* b)
 	return pa < pb ? -1 : pa > pb;
 }
 
-int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
-                  int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap)
+/* the walk state without the probabilities: ref lzma_state.c:29-81 */
+typedef struct { size_t pos; uint8_t ctx_state; uint32_t dists[4]; } wstate;
+static void wstate_advance(wstate* w, orc_packet pk)
+{
+	if (pk.type == ORC_MATCH) {
+		w->dists[3] = w->dists[2]; w->dists[2] = w->dists[1]; w->dists[1] = w->dists[0];
+		w->dists[0] = pk.dist;
+	} else if (pk.type == ORC_LONG_REP) {
+		uint32_t d = w->dists[pk.dist];
+		for (unsigned k = pk.dist; k > 0; k--) w->dists[k] = w->dists[k - 1];
+		w->dists[0] = d;
+	}
+	w->ctx_state = next_ctx_state(w->ctx_state, pk.type);
+	w->pos += pk.len;
+}
+static int wstate_same(const wstate* a, const wstate* b)
+{
+	return a->ctx_state == b->ctx_state && memcmp(a->dists, b->dists, sizeof a->dists) == 0;
+}
+/* the base slab's entry at p while `slab` holds the neighbour: the first value journaled for p */
+static orc_packet base_at(const orc_packet* slab, const journal* jn, size_t p)
+{
+	for (size_t i = 0; i < jn->count; i++) if (jn->d[i].position == p) return jn->d[i].old_packet;
+	return slab[p];
+}
+/* The neighbour's window [target, end): `end` is the first position at which the neighbour's walk
+ * and the base's walk stand on the same byte with the same ctx_state and rep distances, at least
+ * three repair packets after the mutated one (the first three may still turn literals into short
+ * reps, packet_slab_neighbour.c:90-98) -- from there on both parses are coded identically.  n when
+ * they never meet again.  This is where the device's two-pointer walk stops. */
+static size_t window_end(const orc_ctx* c, const orc_packet* slab, const journal* jn, size_t target)
+{
+	wstate bs = { 0, 0, { 0, 0, 0, 0 } };
+	while (bs.pos < target) wstate_advance(&bs, base_at(slab, jn, bs.pos));
+	wstate nb = bs;
+	unsigned count = 0;
+	int first = 1;
+	for (;;) {
+		if (!first && nb.pos == bs.pos && count >= 3 && wstate_same(&nb, &bs)) return nb.pos;
+		if (nb.pos >= c->n && bs.pos >= c->n) return c->n;
+		if (nb.pos <= bs.pos && nb.pos < c->n) {
+			if (!first && count < 8) count++;
+			first = 0;
+			wstate_advance(&nb, slab[nb.pos]);
+		} else {
+			wstate_advance(&bs, base_at(slab, jn, bs.pos));
+		}
+	}
+}
+
+/* status: 1 = ok, 0 = no candidate at the target (main.c:81-84 retries those), -1 = dropped because
+ * its journal needs more than ORC_MAX_JOURNAL distinct positions (the device's journal capacity) */
+int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
+                     int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap, uint32_t* window)
 {
 	ctr_rng r = { seed, step, j, 0 };
 	uint16_t* probs = (uint16_t*)malloc(sizeof(uint16_t) * c->L.total * 2);
@@ -857,12 +916,16 @@ int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, ui
 			for (size_t q = 0; q < i && !seen; q++) seen = jn.d[q].position == jn.d[i].position;
 			distinct += !seen;
 		}
-		if (distinct > ORC_MAX_JOURNAL) ok = 0;
+		if (distinct > ORC_MAX_JOURNAL) ok = -1;
 	}
-	if (cost) *cost = ok ? total : ~0ull;
+	if (cost) *cost = ok == 1 ? total : ~0ull;
+	if (window) {
+		window[0] = (uint32_t)target;
+		window[1] = ok == 1 ? (uint32_t)window_end(c, slab, &jn, target) : 0xFFFFFFFFu;
+	}
 	/* compact the journal: first old value per position + final value, drop no-ops */
 	size_t nd = 0;
-	if (ok && ndiffs) {
+	if (ok == 1 && ndiffs) {
 		orc_diff* tmp = (orc_diff*)malloc(sizeof(orc_diff) * (jn.count ? jn.count : 1));
 		size_t m = 0;
 		for (size_t i = 0; i < jn.count; i++) {
@@ -882,9 +945,14 @@ int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, ui
 		free(tmp);
 	}
 	if (ndiffs) *ndiffs = nd;
-	if (!ok || !keep) journal_undo(&jn, slab);
+	if (ok != 1 || !keep) journal_undo(&jn, slab);
 	free(jn.d); free(probs);
 	return ok;
+}
+int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
+                  int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap)
+{
+	return orc_neighbour_ex(c, slab, seed, step, j, keep, cost, diffs, ndiffs, cap, NULL) == 1;
 }
 
 static uint64_t ceil_sqrt_u64(uint64_t x)
@@ -896,67 +964,104 @@ static uint64_t ceil_sqrt_u64(uint64_t x)
 }
 
 /* one step = K neighbours of the same base slab, then one decision.
- * The decision keeps the shape of main.c:86-96: take the best neighbour if it improves,
- * otherwise (with the reference's i-dependent probability) take a random one.
- * Opt-in, not in the reference (its rule ignores the cost difference): with a
- * temperature t > 0 the random neighbour jr is taken iff u < exp(-delta / t'), u uniform, written
- * with the reference's own log table: delta * 2048 <= t_eff * T[u], u in 1..2047, t_eff = t cooled
- * linearly to 0 over the epoch.  Integer arithmetic throughout. */
+ *
+ * Every evaluation keeps the reference's own rule (main.c:86-87): neighbour j of a step is the
+ * epoch's iteration i = iter0 + (step - step_begin) * K + j and is *acceptable* when it costs less
+ * than the current slab, or when its transition draw  draw % (i*i + 1 + phase*N/2) < sqrt(N)  says so
+ * (with a temperature t > 0, opt-in and not in the reference: instead when u < exp(-delta / t_eff),
+ * in integers through the reference's own log table, delta * 2048 <= t_eff * T[u], t_eff = t cooled
+ * linearly over the epoch).  The current cost of an epoch that has not accepted anything yet is the
+ * exact cost of its starting slab (the reference leaves it at 0 and so accepts its first neighbour
+ * whatever it costs, main.c:74,87).
+ * Acceptable neighbours are ranked by key = (improving ? 0 : 1, cost, j).  What a step takes:
+ *   mode 0 (single): the acceptable neighbour with the smallest key;
+ *   mode 1 (bulk):   every acceptable neighbour whose window [target, end) overlaps no acceptable
+ *                    neighbour of smaller key -- their journals touch disjoint parts of the slab and
+ *                    the walk state between them is the base's, so the result is a valid parse; its
+ *                    exact cost is that of a fresh walk.
+ * trace (nullable) gets 4 u64 per step: smallest acceptable cost (or ~0), neighbours accepted,
+ * acceptable neighbours, current cost after the step. */
 int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_io,
                    uint64_t* best_cost_io, uint64_t seed, uint32_t K, unsigned phase,
-                   uint64_t iters_per_epoch, uint64_t step_begin, uint64_t step_end,
-                   uint64_t* trace, uint64_t* valid_evals)
+                   uint64_t iters_per_epoch, uint64_t iter0, uint64_t step_begin, uint64_t step_end,
+                   const uint8_t* modes, uint64_t* trace, uint64_t* valid_evals, uint64_t* dropped_out)
 {
-	uint64_t cur = *cur_io, best_cost = *best_cost_io, valid = 0;
+	uint64_t cur = *cur_io, best_cost = *best_cost_io, valid = 0, dropped = 0;
 	uint64_t* costs = (uint64_t*)malloc(sizeof(uint64_t) * K);
-	uint64_t thresh = ceil_sqrt_u64(iters_per_epoch);
+	uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * K);
+	uint32_t* win = (uint32_t*)malloc(sizeof(uint32_t) * 2 * K);
+	orc_diff* diffs = (orc_diff*)malloc(sizeof(orc_diff) * ORC_MAX_JOURNAL * (size_t)K);
+	size_t* nd = (size_t*)malloc(sizeof(size_t) * K);
+	uint8_t* take = (uint8_t*)malloc(K);
+	const uint64_t thresh = ceil_sqrt_u64(iters_per_epoch);
 	for (uint64_t s = step_begin; s < step_end; s++) {
-		uint64_t bestc = ~0ull;
-		uint32_t bestj = ~0u;
+		const int bulk = modes ? modes[s - step_begin] : 0;
+		if (cur == 0) cur = orc_cost_slab(c, slab, NULL, NULL, NULL, NULL, NULL);
+		uint64_t minkey = ~0ull;
+		uint32_t minj = ~0u;
+		size_t nacceptable = 0;
 		for (uint32_t j = 0; j < K; j++) {
-			orc_neighbour(c, slab, seed, s, j, 0, &costs[j], NULL, NULL, 0);
-			if (costs[j] != ~0ull) valid++;
-			if (costs[j] < bestc) { bestc = costs[j]; bestj = j; }
-		}
-		uint64_t i = s % iters_per_epoch;
-		uint64_t m = i * i + 1 + (uint64_t)phase * iters_per_epoch / 2;
-		int transition = (orc_draw(seed, s, 0xFFFFFFFFu, 0) % m) < thresh;
-		uint32_t winner = ~0u;
-		if (bestj != ~0u) {
-			if (cur == 0 || bestc < cur) winner = bestj;
-			else if (c->temperature) {
-				uint32_t jr = orc_draw(seed, s, 0xFFFFFFFFu, 1) % K;
-				if (costs[jr] != ~0ull) {
-					const uint32_t u = orc_draw(seed, s, 0xFFFFFFFFu, 0) % 2047u + 1u;
+			const int st = orc_neighbour_ex(c, slab, seed, s, j, 0, &costs[j], diffs + (size_t)j * ORC_MAX_JOURNAL, &nd[j],
+			                                ORC_MAX_JOURNAL, win + 2 * (size_t)j);
+			keys[j] = ~0ull;
+			if (st == -1) dropped++;
+			if (st != 1) continue;
+			valid++;
+			uint64_t i = iter0 + (s - step_begin) * K + j;
+			if (i > 0x7FFFFFFFull) i = 0x7FFFFFFFull;
+			const uint32_t draw = orc_draw(seed, s, 0xFFFFFFFFu, 2u + j);
+			int ok = costs[j] < cur;
+			if (!ok) {
+				if (c->temperature) {
+					const uint32_t u = draw % 2047u + 1u;
 					const uint64_t ic = i < iters_per_epoch ? i : iters_per_epoch;
 					const uint64_t t_eff = c->temperature * (iters_per_epoch - ic) / iters_per_epoch;
-					const uint64_t delta = costs[jr] - cur; /* the best neighbour did not improve: >= 0 */
-					if (delta * 2048u <= t_eff * (uint64_t)orc_cost_table()[u]) winner = jr;
+					ok = (costs[j] - cur) * 2048u <= t_eff * (uint64_t)orc_cost_table()[u];
+				} else {
+					const uint64_t m = i * i + 1 + (uint64_t)phase * iters_per_epoch / 2;
+					ok = ((uint64_t)draw % m) < thresh;
 				}
-			} else if (transition) {
-				uint32_t jr = orc_draw(seed, s, 0xFFFFFFFFu, 1) % K;
-				if (costs[jr] != ~0ull) winner = jr;
+			}
+			if (!ok) continue;
+			nacceptable++;
+			keys[j] = ((costs[j] < cur ? 0ull : 1ull) << 63) | (costs[j] << 20) | j;
+			if (keys[j] < minkey) { minkey = keys[j]; minj = j; }
+		}
+		size_t ntaken = 0;
+		memset(take, 0, K);
+		if (!bulk) {
+			if (minj != ~0u) { take[minj] = 1; ntaken = 1; }
+		} else {
+			for (uint32_t j = 0; j < K; j++) {
+				if (keys[j] == ~0ull) continue;
+				int lose = 0;
+				for (uint32_t i = 0; i < K && !lose; i++)
+					lose = keys[i] < keys[j] && win[2 * i] < win[2 * j + 1] && win[2 * j] < win[2 * i + 1];
+				if (!lose) { take[j] = 1; ntaken++; }
 			}
 		}
-		if (winner != ~0u) {
-			uint64_t cst;
-			orc_neighbour(c, slab, seed, s, winner, 1, &cst, NULL, NULL, 0);
-			cur = cst;
+		for (uint32_t j = 0; j < K; j++) {
+			if (!take[j]) continue;
+			for (size_t e = 0; e < nd[j]; e++) slab[diffs[(size_t)j * ORC_MAX_JOURNAL + e].position] = diffs[(size_t)j * ORC_MAX_JOURNAL + e].new_packet;
+		}
+		if (ntaken) {
+			cur = (!bulk) ? costs[minj] : orc_cost_slab(c, slab, NULL, NULL, NULL, NULL, NULL);
 			if (best_cost == 0 || cur < best_cost) {
 				best_cost = cur;
 				memcpy(best, slab, sizeof(orc_packet) * c->n);
 			}
 		}
 		if (trace) {
-			trace[4 * (s - step_begin) + 0] = bestc;
-			trace[4 * (s - step_begin) + 1] = winner == ~0u ? ~0ull : winner;
-			trace[4 * (s - step_begin) + 2] = winner != ~0u;
+			trace[4 * (s - step_begin) + 0] = minj == ~0u ? ~0ull : costs[minj];
+			trace[4 * (s - step_begin) + 1] = ntaken;
+			trace[4 * (s - step_begin) + 2] = nacceptable;
 			trace[4 * (s - step_begin) + 3] = cur;
 		}
 	}
 	*cur_io = cur; *best_cost_io = best_cost;
 	if (valid_evals) *valid_evals = valid;
-	free(costs);
+	if (dropped_out) *dropped_out = dropped;
+	free(costs); free(keys); free(win); free(diffs); free(nd); free(take);
 	return 0;
 }
 

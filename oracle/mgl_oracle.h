@@ -81,12 +81,22 @@ uint32_t orc_draw(uint64_t seed, uint64_t step, uint32_t j, uint32_t n);
  * de-duplicated by position and sorted ascending. */
 int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
                   int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap);
-/* Run `steps` batched steps of K neighbours; mirrors mgl_sa_run.  trace (nullable) gets
- * 4 u64 per step: best neighbour cost, winner index (or ~0), accepted flag, current cost. */
+/* the same with the neighbour's status (1 ok, 0 no candidate, -1 dropped by the 64-entry journal
+ * capacity of the device) and its window: window[0] = target position, window[1] = first position
+ * from which neighbour and base are coded identically again (n if never; ~0 when not ok) */
+int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
+                     int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap, uint32_t* window);
+/* Run batched steps [step_begin, step_end) of K neighbours; mirrors mgl_sa_run.  iter0 = evaluations
+ * already made in this epoch (the reference's i); modes (nullable = all 0): per step 0 = take the
+ * best acceptable neighbour, 1 = take every acceptable neighbour that is the best of its window.
+ * trace (nullable) gets 4 u64 per step: smallest acceptable cost (or ~0), neighbours accepted,
+ * acceptable neighbours, current cost after the step. */
 int orc_sa_batched(orc_ctx* c, orc_packet* slab_io, orc_packet* best_io, uint64_t* cur_io,
                    uint64_t* best_cost_io, uint64_t seed, uint32_t K, unsigned phase,
-                   uint64_t iters_per_epoch, uint64_t step_begin, uint64_t step_end,
-                   uint64_t* trace, uint64_t* valid_evals);
+                   uint64_t iters_per_epoch, uint64_t iter0, uint64_t step_begin, uint64_t step_end,
+                   const uint8_t* modes, uint64_t* trace, uint64_t* valid_evals, uint64_t* dropped);
+/* cap on the match-index hits a top-K query enumerates (nearest first); mirrors mgl_sa_config.max_bucket_scan */
+void orc_set_max_bucket_scan(orc_ctx* c, uint32_t m);
 
 /* Opt-in Metropolis rule for orc_sa_batched (0 = the reference's rule); mirrors mgl_sa_set_temperature. */
 void orc_set_temperature(orc_ctx* c, uint64_t temperature);

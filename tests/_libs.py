@@ -102,20 +102,26 @@ class Oracle:
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
             L.orc_sa_batched.restype = C.c_int
             L.orc_sa_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                                         C.c_uint32, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
-                                         C.c_void_p]
+                                         C.c_uint32, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.orc_neighbour_ex.restype = C.c_int
+            L.orc_neighbour_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+            L.orc_set_max_bucket_scan.argtypes = [C.c_void_p, C.c_uint32]
             L.orc_set_temperature.argtypes = [C.c_void_p, C.c_uint64]
             L.orc_emit.restype = C.c_size_t
             L.orc_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
             cls._lib = L
         return cls._lib
 
-    def __init__(self, data: bytes, lc=0, lp=0, pb=0, dict_limit=0):
+    def __init__(self, data: bytes, lc=0, lp=0, pb=0, dict_limit=0, max_bucket_scan=0):
         self.L = self.lib()
         self.data = np.frombuffer(bytes(data), dtype=np.uint8).copy()
         self.n = len(self.data)
         self.h = self.L.orc_new(ptr(self.data), self.n, lc, lp, pb, dict_limit)
         self.nprobs = self.L.orc_num_probs(self.h)
+        if max_bucket_scan:
+            self.L.orc_set_max_bucket_scan(self.h, max_bucket_scan)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -189,15 +195,33 @@ class Oracle:
         assert nd.value <= cap
         return bool(ok), cost.value, diffs[: nd.value].copy()
 
+    def neighbour_ex(self, slab, seed, step, j, keep=False, cap=4096):
+        """status (1 ok / 0 no candidate / -1 dropped by the journal capacity), cost, diffs, (target, window end)"""
+        cost = C.c_uint64(0)
+        nd = C.c_size_t(0)
+        diffs = np.zeros(cap, dtype=DIFF)
+        win = np.zeros(2, dtype=np.uint32)
+        st = self.L.orc_neighbour_ex(self.h, ptr(slab), seed, step, j, int(keep), C.addressof(cost), ptr(diffs),
+                                     C.addressof(nd), cap, ptr(win))
+        return st, cost.value, diffs[: min(nd.value, cap)].copy(), (int(win[0]), int(win[1]))
+
     def set_temperature(self, temperature: int):
         self.L.orc_set_temperature(self.h, temperature)
 
-    def sa_batched(self, slab, best, cur, best_cost, seed, K, phase, iters_per_epoch, step_begin, step_end):
-        trace = np.zeros(4 * max(1, step_end - step_begin), dtype=np.uint64)
-        cur_c, best_c, valid = C.c_uint64(cur), C.c_uint64(best_cost), C.c_uint64(0)
+    def sa_batched(self, slab, best, cur, best_cost, seed, K, phase, iters_per_epoch, step_begin, step_end,
+                   iter0=0, modes=None):
+        """modes: None = every step takes the single best acceptable neighbour; else one byte per step
+        (0 single, 1 bulk).  trace columns: smallest acceptable cost, accepted, acceptable, current cost."""
+        nsteps = max(1, step_end - step_begin)
+        trace = np.zeros(4 * nsteps, dtype=np.uint64)
+        m = None if modes is None else np.ascontiguousarray(modes, dtype=np.uint8)
+        assert m is None or len(m) >= step_end - step_begin
+        cur_c, best_c, valid, dropped = C.c_uint64(cur), C.c_uint64(best_cost), C.c_uint64(0), C.c_uint64(0)
         self.L.orc_sa_batched(self.h, ptr(slab), ptr(best), C.addressof(cur_c), C.addressof(best_c), seed, K, phase,
-                              iters_per_epoch, step_begin, step_end, ptr(trace), C.addressof(valid))
-        return dict(cur=cur_c.value, best=best_c.value, trace=trace.reshape(-1, 4).copy(), valid=valid.value)
+                              iters_per_epoch, iter0, step_begin, step_end, ptr(m), ptr(trace), C.addressof(valid),
+                              C.addressof(dropped))
+        return dict(cur=cur_c.value, best=best_c.value, trace=trace.reshape(-1, 4).copy(), valid=valid.value,
+                    dropped=dropped.value)
 
     def emit(self, slab) -> bytes:
         cap = 2 * self.n + 1024

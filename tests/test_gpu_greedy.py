@@ -70,7 +70,7 @@ def as_list(slab):
     ("n1", b"x", 16),
 ])
 def test_greedy_slab_matches_the_rule(name, data, cand):
-    sa = binding.SA(data, neighbours_per_step=16)
+    sa = binding.SA(data, accept="single", neighbours_per_step=16)
     sa.seed_greedy(cand)
     cur, cost = sa.current()
     assert as_list(cur) == greedy_rule(data, cand), name
@@ -85,7 +85,7 @@ def test_greedy_slab_matches_the_rule(name, data, cand):
 def test_greedy_tail_entries_with_short_lookahead():
     """The last positions cannot hold 4 bytes: only the 2-byte source is consulted there."""
     data = b"abcdabcdab"
-    sa = binding.SA(data, neighbours_per_step=16)
+    sa = binding.SA(data, accept="single", neighbours_per_step=16)
     sa.seed_greedy(64)
     cur, _ = sa.current()
     got = as_list(cur)
@@ -97,7 +97,7 @@ def test_greedy_lazy_step():
     """'bcde' occurs earlier and so does 'abc': at the 'a' the next position starts a longer match,
     so the 'a' stays a literal."""
     data = b"abcX" + b"bcdefgY" + b"abcdefg"
-    sa = binding.SA(data, neighbours_per_step=16)
+    sa = binding.SA(data, accept="single", neighbours_per_step=16)
     sa.seed_greedy(64)
     cur, _ = sa.current()
     got = as_list(cur)
@@ -111,7 +111,7 @@ def test_search_continues_from_the_seed_like_the_oracle():
     """After seeding, mgl_sa_run is the oracle's batched SA started from that slab."""
     data = corpus.enwik_like(3000, 0x33)
     n, K, seed, steps = len(data), 64, 99, 40
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed, iters_per_epoch=steps)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, iters_per_epoch=steps)
     sa.seed_greedy(32)
     cur, _ = sa.current()
     o = Oracle(data, dict_limit=0x400000)
@@ -132,7 +132,7 @@ def test_greedy_seed_beats_the_literal_start_at_equal_budget():
     data = corpus.enwik_like(30000, 0x34)
     res = {}
     for greedy in (False, True):
-        sa = binding.SA(data, neighbours_per_step=1024, seed=3)
+        sa = binding.SA(data, accept="single", neighbours_per_step=1024, seed=3)
         if greedy:
             sa.seed_greedy(256)
         st = sa.run(300)
@@ -167,11 +167,11 @@ def test_metropolis_rule_trajectory_vs_oracle():
     o = Oracle(data, dict_limit=0x400000)
     runs = {}
     for t in (0, temp):
-        sa = binding.SA(data, neighbours_per_step=K, seed=seed, iters_per_epoch=steps)
+        sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, iters_per_epoch=steps * K)
         sa.set_temperature(t)
         o.set_temperature(t)
         slab, best = literal_slab(n), literal_slab(n)
-        ref = o.sa_batched(slab, best, 0, 0, seed, K, 0, steps, 0, steps)
+        ref = o.sa_batched(slab, best, 0, 0, seed, K, 0, steps * K, 0, steps)
         costs = []
         for s in range(steps):
             st = sa.run(1)
@@ -188,7 +188,7 @@ def test_metropolis_rule_trajectory_vs_oracle():
     worse = sum(1 for a, b in zip(runs[temp], runs[temp][1:]) if b > a)
     assert worse > 0 and runs[temp] != runs[0]
     with pytest.raises(binding.MglError):
-        sa = binding.SA(data, neighbours_per_step=K)
+        sa = binding.SA(data, accept="single", neighbours_per_step=K)
         try:
             sa.set_temperature(1 << 40)
         finally:
@@ -212,8 +212,8 @@ def test_greedy_seed_under_every_engine_option(kw):
     same slab, same costs as the default engine, step by step; epochs restart from the best slab."""
     data = corpus.enwik_like(5000, 0x38)
     props = {k: v for k, v in kw.items() if k in ("lc", "pb")}
-    ref = binding.SA(data, neighbours_per_step=96, seed=21, iters_per_epoch=50, **props)
-    sa = binding.SA(data, neighbours_per_step=96, seed=21, iters_per_epoch=50, **kw)
+    ref = binding.SA(data, accept="single", neighbours_per_step=96, seed=21, iters_per_epoch=50, **props)
+    sa = binding.SA(data, accept="single", neighbours_per_step=96, seed=21, iters_per_epoch=50, **kw)
     for s in (ref, sa):
         s.seed_greedy(48)
     a, ca = ref.current()

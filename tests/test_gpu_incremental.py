@@ -94,7 +94,7 @@ def check_base(sa, o, slab, data):
 def test_base_structures_match_oracle_trace(name, serial_build, golden, golden_input):
     data = golden_input(name)
     n = len(data)
-    sa = binding.SA(data, neighbours_per_step=8, serial_build=serial_build)
+    sa = binding.SA(data, accept="single", neighbours_per_step=8, serial_build=serial_build)
     o = Oracle(data)
     slabs = [literal_slab(n)]
     if name in golden["evolved_walks"]:
@@ -113,8 +113,8 @@ def test_engines_agree_on_c2_neighbours():
     equals the full-walk engine (which equals the oracle, test_gpu_parity.py)."""
     data, _ = corpus.config_input("c2")
     K, seed = 1024, 4242
-    inc = binding.SA(data, neighbours_per_step=K, seed=seed)
-    full = binding.SA(data, neighbours_per_step=K, seed=seed, fullwalk=True)
+    inc = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed)
+    full = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, fullwalk=True)
     for rounds in range(3):
         for step in (rounds * 10, rounds * 10 + 1):
             ci, ni, di = inc.neighbours(step)
@@ -167,8 +167,8 @@ def test_incremental_accept_equals_rebuild(name, K, steps, golden, golden_input)
     """After every accepted step the incrementally maintained base (bitmaps, special-state
     records, chains, dense checkpoints) is identical to one rebuilt from the slab."""
     data = golden_input(name)
-    inc = binding.SA(data, neighbours_per_step=K, seed=5, iters_per_epoch=steps)
-    ref = binding.SA(data, neighbours_per_step=8, seed=5)
+    inc = binding.SA(data, accept="single", neighbours_per_step=K, seed=5, iters_per_epoch=steps)
+    ref = binding.SA(data, accept="single", neighbours_per_step=8, seed=5)
     o = Oracle(data, dict_limit=0x400000)
     accepted = 0
     for s in range(steps):
@@ -191,8 +191,8 @@ def test_epoch_snapshots_equal_rebuild(name, K, golden, golden_input):
     (MGL_F_NO_SNAPSHOTS), across main.c:69-77's phase/epoch schedule."""
     data = golden_input(name)
     steps = (len(data) + K - 1) // K
-    a = binding.SA(data, neighbours_per_step=K, seed=11, iters_per_epoch=len(data))
-    b = binding.SA(data, neighbours_per_step=K, seed=11, iters_per_epoch=len(data), snapshots=False)
+    a = binding.SA(data, accept="single", neighbours_per_step=K, seed=11, iters_per_epoch=len(data))
+    b = binding.SA(data, accept="single", neighbours_per_step=K, seed=11, iters_per_epoch=len(data), snapshots=False)
     o = Oracle(data, dict_limit=0x400000)
     for phase in range(3):
         for epoch in range(3):
@@ -232,8 +232,8 @@ def test_parallel_build_equals_serial_build(cfg, size, K, steps):
     inside a block and one byte into a new one."""
     data, _ = corpus.config_input(cfg, size)
     props = dict(pb=2, max_bucket_scan=512) if cfg == "c5" else {}
-    par = binding.SA(data, neighbours_per_step=K, seed=3, **props)
-    ser = binding.SA(data, neighbours_per_step=8, seed=3, serial_build=True, snapshots=False, **props)
+    par = binding.SA(data, accept="single", neighbours_per_step=K, seed=3, **props)
+    ser = binding.SA(data, accept="single", neighbours_per_step=8, seed=3, serial_build=True, snapshots=False, **props)
     o = Oracle(data, dict_limit=0x400000, **({"pb": 2} if cfg == "c5" else {}))
     for round_ in range(2):
         cur, cost = par.current()
@@ -256,7 +256,7 @@ def test_parallel_build_serial_segment_path():
     the segments whose bracket did not close.  That never happens on these inputs, so force it
     (mgl_debug_set key 1) and require the same structures and cost."""
     data, _ = corpus.config_input("c2", 60000)
-    a = binding.SA(data, neighbours_per_step=512, seed=9)
+    a = binding.SA(data, accept="single", neighbours_per_step=512, seed=9)
     a.run(30)
     cur, cost = a.current()
     want = canonical_base(a, cur)
@@ -281,12 +281,12 @@ def test_launch_forms_give_one_trajectory(monkeypatch):
     K = 4096
     monkeypatch.delenv("MGL_NO_SPLIT", raising=False)
     monkeypatch.delenv("MGL_NO_ADAPT", raising=False)
-    adaptive = binding.SA(data, neighbours_per_step=K)
+    adaptive = binding.SA(data, accept="single", neighbours_per_step=K)
     monkeypatch.setenv("MGL_NO_ADAPT", "1")
-    split = binding.SA(data, neighbours_per_step=K)
+    split = binding.SA(data, accept="single", neighbours_per_step=K)
     monkeypatch.delenv("MGL_NO_ADAPT")
     monkeypatch.setenv("MGL_NO_SPLIT", "1")
-    single = binding.SA(data, neighbours_per_step=K)
+    single = binding.SA(data, accept="single", neighbours_per_step=K)
     monkeypatch.delenv("MGL_NO_SPLIT")
     for s in range(75):
         if s % 5 == 0 or 44 <= s <= 62:
@@ -312,7 +312,7 @@ def test_second_pass_takes_what_overflows_small_lists():
     data = corpus.lorem(3000)
     runs = []
     for cap in (0, 16):
-        sa = binding.SA(data, neighbours_per_step=96, seed=5, iters_per_epoch=60)
+        sa = binding.SA(data, accept="single", neighbours_per_step=96, seed=5, iters_per_epoch=60)
         if cap:
             assert sa.L.mgl_debug_set(sa.h, 2, cap) == 0
         costs, second = [], 0

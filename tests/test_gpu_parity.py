@@ -134,39 +134,93 @@ def test_neighbours_bit_exact_vs_oracle(name, fullwalk, golden, golden_input):
             _check_neighbours(sa, o, base, seed, step, K)
 
 
-@ENGINES
-def test_sa_run_trajectory_vs_oracle(fullwalk):
-    """mgl_sa_run step by step against orc_sa_batched: same winner, same accept decision,
-    same current/best cost every step, same final slabs; the stream decodes."""
+@pytest.mark.parametrize("fullwalk,accept", [(False, "single"), (True, "single"), (False, "bulk"), (False, "auto")],
+                         ids=["incremental-single", "fullwalk-single", "bulk", "auto"])
+def test_sa_run_trajectory_vs_oracle(fullwalk, accept):
+    """mgl_sa_run against orc_sa_batched: same accept decisions, same current/best cost every step, same
+    final slabs; the stream decodes.  Single steps take the best acceptable neighbour, bulk steps every
+    acceptable neighbour that is the best of its window; "auto" is a run of both, replayed in the oracle
+    with the modes the library chose."""
     data = corpus.lorem(1800)
     n = len(data)
     K, seed, steps = 48, 1673551, 60
-    ipe = steps  # iterations per epoch: the oracle helper derives i = gstep % ipe
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed, iters_per_epoch=ipe, fullwalk=fullwalk)
+    ipe = steps * K  # evaluations per epoch: neighbour j of in-epoch step s is the reference's iteration s K + j
+    sa = binding.SA(data, accept=accept, bulk_threshold=6, neighbours_per_step=K, seed=seed, iters_per_epoch=ipe, fullwalk=fullwalk)
     o = Oracle(data, dict_limit=0x400000)
     slab, best = literal_slab(n), literal_slab(n)
-    ref = o.sa_batched(slab, best, 0, 0, seed, K, 0, ipe, 0, steps)
-    evals = 0
-    for s in range(steps):
-        st = sa.run(1)
-        evals += st["evaluations"]
-        assert st["current_cost"] == int(ref["trace"][s, 3]), s
-    assert evals == ref["valid"]
+    evals = dropped = 0
+    if accept == "auto":
+        st = sa.run(steps)
+        modes = sa.step_modes()
+        assert len(modes) == steps and 0 < modes.sum() < steps, modes  # a mix of both kinds of step
+        assert st["bulk_steps"] == modes.sum()
+        ref = o.sa_batched(slab, best, 0, 0, seed, K, 0, ipe, 0, steps, modes=modes)
+        evals, dropped = st["evaluations"], st["dropped_neighbours"]
+        assert st["current_cost"] == ref["cur"]
+        assert st["accepted"] == int(ref["trace"][:, 1].sum())
+    else:
+        modes = np.full(steps, 1 if accept == "bulk" else 0, dtype=np.uint8)
+        ref = o.sa_batched(slab, best, 0, 0, seed, K, 0, ipe, 0, steps, modes=modes)
+        for s in range(steps):
+            st = sa.run(1)
+            evals += st["evaluations"]
+            dropped += st["dropped_neighbours"]
+            assert st["current_cost"] == int(ref["trace"][s, 3]), s
+            assert st["accepted"] == int(ref["trace"][s, 1]), s
+        if accept == "bulk":
+            assert int(ref["trace"][:, 1].max()) > 1  # steps that took several neighbours at once
+    assert evals == ref["valid"] and dropped == ref["dropped"]
     cur, cur_cost = sa.current()
     bst, best_cost = sa.best()
     assert cur_cost == ref["cur"] and best_cost == ref["best"]
     assert as_list(cur) == as_list(slab) and as_list(bst) == as_list(best)
+    assert sa.cost_slab(cur)["total"] == cur_cost  # the device's independent full walk
     stream = binding.emit_stream(data, bst)
     assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
     # a second epoch from the best slab (main.c:75-77, phase 1): the global step keeps
     # counting, the in-epoch iteration restarts, the current cost is forgotten
     sa.begin_epoch(1, from_best=True)
     slab2 = best.copy()
-    ref2 = o.sa_batched(slab2, best, 0, ref["best"], seed, K, 1, ipe, steps, steps + 25)
     st = sa.run(25)
+    ref2 = o.sa_batched(slab2, best, 0, ref["best"], seed, K, 1, ipe, steps, steps + 25, modes=sa.step_modes())
     assert st["steps"] == 25 and st["current_cost"] == ref2["cur"] and st["best_cost"] == ref2["best"]
     cur, _ = sa.current()
     assert as_list(cur) == as_list(slab2)
+    bst, _ = sa.best()
+    assert as_list(bst) == as_list(best)
+    sa.close()
+
+
+def test_windows_and_drop_counter_vs_oracle():
+    """Every neighbour's window [target, end) -- what a bulk step's selection works on -- equals the
+    oracle's, on both engines, on a repetitive input whose repairs run long; and the count of
+    neighbours dropped by the 64-entry journal equals the oracle's (the reference's undo stack is
+    unbounded, packet_slab_undo_stack.c:70-77: such neighbours are lost here, and counted)."""
+    data = corpus.lorem(3000)
+    n, K, seed = len(data), 128, 5
+    o = Oracle(data, dict_limit=0x400000)
+    slab, best = literal_slab(n), literal_slab(n)
+    o.sa_batched(slab, best, 0, 0, seed, K, 0, n, 0, 10, modes=np.ones(10, dtype=np.uint8))
+    for fullwalk in (False, True):
+        sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, fullwalk=fullwalk)
+        sa.set_slab(P(slab))
+        costs, nd, _ = sa.neighbours(777)
+        win = sa.debug_dump(21, np.uint32).reshape(-1, 2)
+        ndrop = 0
+        for j in range(K):
+            st, cost, diffs, w = o.neighbour_ex(slab, seed, 777, j)
+            ndrop += st == -1
+            assert (int(costs[j]) == cost) and (st == 1) == (int(costs[j]) != binding.INVALID_COST), j
+            if st == 1:
+                assert (int(win[j, 0]), int(win[j, 1])) == w, (j, win[j], w)
+        sa.close()
+    # the drop counter through mgl_sa_run (one single step from the same slab, both engines agree with the oracle)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, iters_per_epoch=n)
+    sa.set_slab(P(slab))
+    st = sa.run(1)
+    s2, b2 = slab.copy(), best.copy()
+    ref = o.sa_batched(s2, b2, 0, 0, seed, K, 0, n, 0, 1)
+    assert st["dropped_neighbours"] == ref["dropped"] and st["evaluations"] == ref["valid"]
     sa.close()
 
 
@@ -176,7 +230,7 @@ def test_tiny_and_incompressible_inputs(data, fullwalk):
     """Edge cases: inputs where few or no neighbours exist (the reference spins forever at
     main.c:81-84 there); failed generates come back as UINT64_MAX and nothing crashes."""
     K, seed = 16, 5
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed, fullwalk=fullwalk)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, fullwalk=fullwalk)
     o = Oracle(data, dict_limit=0x400000)
     base = literal_slab(len(data))
     assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]
@@ -196,7 +250,7 @@ def test_full_size_c2_properties():
     data, _ = corpus.config_input("c2")
     n = len(data)
     K, seed = 4096, 1673551
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed)
     o = Oracle(data, dict_limit=0x400000)
     base = literal_slab(n)
     costs, nd, diffs = sa.neighbours(0)
@@ -226,7 +280,7 @@ def test_pb2_elf_shaped_properties():
     data, _ = corpus.config_input("c5", 65536)
     data = data[16384:32768]
     K, seed = 256, 11
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed, pb=2, max_bucket_scan=0)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, pb=2, max_bucket_scan=0)
     o = Oracle(data, pb=2, dict_limit=0x400000)
     base = literal_slab(len(data))
     assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]
@@ -247,7 +301,7 @@ def test_match_index_built_on_device(cfg, size):
     """substring_enumerator.c:26-47: positions bucketed by leading bigram, ascending inside a
     bucket.  The device builds it with a stable two-pass counting sort (mgl_index.hip)."""
     data, _ = corpus.config_input(cfg, size)
-    sa = binding.SA(data, neighbours_per_step=8)
+    sa = binding.SA(data, accept="single", neighbours_per_step=8)
     d = np.frombuffer(data, dtype=np.uint8).astype(np.uint32)
     keys = (d[:-1] << 8) | d[1:]
     want_pos = np.argsort(keys, kind="stable").astype(np.uint32)
@@ -277,7 +331,7 @@ def test_literal_context_and_position_bits(lc, lp, pb):
     stream must decode with liblzma."""
     data, _ = corpus.config_input("c2", 12000)
     K, seed = 192, 5
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed, lc=lc, lp=lp, pb=pb)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, lc=lc, lp=lp, pb=pb)
     o = Oracle(data, lc=lc, lp=lp, pb=pb, dict_limit=0x400000)
     base = literal_slab(len(data))
     assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]
@@ -307,7 +361,7 @@ def test_full_size_c3_properties():
     data, _ = corpus.config_input("c3")
     n = len(data)
     K, seed = 16384, 1673551
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed)
     o = Oracle(data, dict_limit=0x400000)
     base = literal_slab(n)
     assert sa.current()[1] == o.cost_slab(base)["total"]
@@ -340,13 +394,13 @@ def test_evolved_c2_neighbours_vs_oracle():
     and reps on the walk: the repair path and the second pass are exercised), both engines."""
     data, _ = corpus.config_input("c2")
     K, seed = 4096, 1673551
-    sa = binding.SA(data, neighbours_per_step=K, seed=seed)
+    sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed)
     o = Oracle(data, dict_limit=0x400000)
     sa.run(400)
     cur, cost = sa.current()
     curo = cur.astype(literal_slab(1).dtype)
     assert cost == o.cost_slab(curo)["total"]
-    full = binding.SA(data, neighbours_per_step=K, seed=seed, fullwalk=True)
+    full = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, fullwalk=True)
     full.set_slab(cur)
     ca, _, _ = sa.neighbours(400, want_diffs=False)
     cf, _, _ = full.neighbours(400, want_diffs=False)

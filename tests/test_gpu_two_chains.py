@@ -20,7 +20,7 @@ def _worker(rank, world, port, out):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     data = corpus.enwik_like(4000, 0x51)
-    sa = binding.SA(data, neighbours_per_step=256, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=len(data))
+    sa = binding.SA(data, accept="single", neighbours_per_step=256, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=len(data))
     sa.run(10 + 30 * rank)  # rank 1 searches longer: it should win
     _, mine = sa.best()
     winner, wcost = multi_gpu.exchange_best(sa, dist)

@@ -3,52 +3,82 @@
 
   python bench.py --gpus N --steps K --warmup W        (N=1: plain python; N>1: torchrun)
 
-One "step" = one pass of the hot path over one batch: K_nb candidate neighbours of the
-current slab generated and costed exactly, one accept decision, base structures refreshed.
-Workload at every N = BASELINE configs[1]: enwik5-shaped 100 000 B (synthetic, seeded --
-no corpora exist offline), 4 096 neighbours/step, lc=lp=pb=0, top-K 20.  One chain per GPU
-with its own RNG stream (weak scaling); the path has no data-path collective except the
-per-epoch best-slab exchange (one 8-byte RCCL all-reduce + a broadcast), done once inside
-the timed region.
+One "step" = one pass of the hot path over one batch: K_nb candidate neighbours of the current slab
+generated and costed exactly (each cost = the u64 perplexity of one complete parse of the input), one
+decision, the base structures brought up to date.
 
-Rank 0 prints ONE JSON line.  `value` = neighbour evaluations that produced a cost, summed
-over all ranks, / max-over-ranks wall time of the K timed steps (inputs resident in HBM
-before the timed region).  `roofline` prices the dominant kernels (the two halves of the
-incremental neighbour evaluation, k_neighbours2<PICK> + <REST>, with their second pass) with SURVEY
-section 8d's algorithmic bytes B_eval = N + 12*P per evaluation against 8 TB/s, using the
-average duration from HIP events recorded on the library's own stream.  NOTE: the kernel is
-incremental -- it prices only the window a neighbour changes and re-joins the base model's
-trajectory -- so it does not move B_eval bytes per evaluation; `achieved` is the metric's
-algorithmic figure, `traffic` (when collected with rocprofv3 --pmc) the real HBM bytes.
-`cpu_baseline` times the compiled reference (oracle/_ref, kind "reference") or else the CPU
-oracle (kind "port") on a bounded sample of the same workload, 1 thread, rank 0, N=1 only.
+Workload.  N = 1: BASELINE configs[2], the largest single-GPU configuration -- dickens-shaped 10 192 446 B
+(synthetic, seeded: no corpora exist offline), 16 384 neighbours/step, lc=lp=pb=0, top-K 20.  N > 1:
+configs[3], one independent chain per GPU on an enwik8-shaped 100 000 000 B input, 16 384 neighbours/step
+(weak scaling), with the per-epoch best-slab exchange (one 8-byte RCCL all-reduce + one broadcast of the
+packed slab, from the C library) done once inside the timed region.  `--config` selects another one.
+
+State measured.  The configs are long runs (10^5 .. 10^6 steps); what such a run does almost all of the time is
+step an *evolved* slab.  So the set-up phase first runs `--prepare-steps` search steps from the all-literal slab
+in the library's default accept mode (bulk steps while they pay, then single steps; untimed, reported under
+"prepare"), then W untimed warm-up steps, then exactly K timed steps, bracketed by barrier + device synchronise.
+`value` = neighbour evaluations that produced a cost, summed over ranks, / max-over-ranks wall time.  The rate on
+the young slab (first steps from the all-literal slab) is reported beside it under "young_slab".
+
+`roofline`: the dominant kernels are the three launches of the incremental neighbour evaluation (pick, window
+walk, chain re-simulation).  `achieved` = their HBM traffic per step from rocprofv3 PMC counters (FETCH_SIZE and
+WRITE_SIZE in their own passes, fetch doubled per the gfx950 note = an upper bound; profiles/<tag>_pmc_<cfg>.json,
+raw rows beside it) / their duration per step measured live here with HIP events on the library's streams;
+`frac` = achieved / 8 TB/s.  The kernels are latency-bound, not HBM-bound: the wait / issue counters of the same
+profile are copied into `limiter`.  `algorithmic_equiv_gbs` is SURVEY 8d's figure (N + 12 P bytes per evaluation,
+as if every evaluation streamed the whole parse, which the incremental kernels do not do): not a fraction of anything.
+`cpu_baseline`: the compiled reference (oracle/_ref, kind "reference") or else the CPU oracle (kind "port") on a
+bounded sample of the same input, rank 0, N = 1 only.  `gates`: SURVEY 8d's correctness gates, taken after the
+timed region, and the size comparison with the reference at equal evaluations and at equal steps.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+PROFILE_TAG = "r02"
+DEFAULT_K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}
+DEFAULT_PREPARE = {"c1": 64, "c2": 400, "c3": 700, "c4": 700, "c5": 400}
+DOMINANT = ("k_neighbours2<false, 1>", "k_neighbours2<false, 2>", "k_sim")
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _ref_engine(data):
+    import _libs
+
+    if _libs.Ref.available():
+        return _libs.Ref(data), "reference", _libs.Ref.lib().ref_srand
+    return _libs.Oracle(data), "port", _libs.Oracle.lib().orc_srand
 
 
 def cpu_baseline(data, seconds):
-    """Reference-semantics SA iterations (main.c:78-102) on one host thread."""
+    """Reference-semantics SA iterations (main.c:78-102) on one host thread, from the all-literal slab."""
     import _libs
 
     n = len(data)
-    if _libs.Ref.available():
-        eng, kind, seed_fn = _libs.Ref(data), "reference", _libs.Ref.lib().ref_srand
-    else:
-        eng, kind, seed_fn = _libs.Oracle(data), "port", _libs.Oracle.lib().orc_srand
+    eng, kind, seed_fn = _ref_engine(data)
     slab, best = _libs.literal_slab(n), _libs.literal_slab(n)
     seed_fn(1673551)
     cur = bst = 0
-    done, chunk = 0, 100
+    done = 0
+    chunk = 100 if n <= (1 << 20) else 4
     t0 = time.perf_counter()
     while True:
         r = eng.sa_iters(slab, best, cur, bst, 0, n, done, done + chunk)
@@ -57,72 +87,124 @@ def cpu_baseline(data, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or done >= 40000:
             break
-    return dict(value=done / el, unit="evals/s", cores=1, kind=kind,
+    return dict(value=done / el, unit="evals/s", cores=1, kind=kind, nproc=os.cpu_count(), cpu=cpu_model(),
                 sample=f"{done} SA iterations (seed 1673551, from the all-literal slab) of the same "
-                       f"{n} B input in {el:.1f} s on 1 thread")
+                       f"{n} B input in {el:.1f} s on 1 thread", iterations=done, best_cost=bst, est_bytes_best=18 + bst / 16384)
 
 
 def _cpu_worker(args):
     data, seconds, seed = args
     import _libs
+
     n = len(data)
-    eng = _libs.Ref(data) if _libs.Ref.available() else _libs.Oracle(data)
-    (_libs.Ref.lib().ref_srand if _libs.Ref.available() else _libs.Oracle.lib().orc_srand)(seed)
+    eng, _, seed_fn = _ref_engine(data)
+    seed_fn(seed)
     slab, best = _libs.literal_slab(n), _libs.literal_slab(n)
     cur = bst = 0
+    chunk = 100 if n <= (1 << 20) else 2
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        r = eng.sa_iters(slab, best, cur, bst, 0, n, done, done + 100)
+        r = eng.sa_iters(slab, best, cur, bst, 0, n, done, done + chunk)
         cur, bst = r["cur"], r["best"]
-        done += 100
+        done += chunk
     return done, time.perf_counter() - t0
 
 
 def cpu_baseline_all_cores(data, seconds):
-    """Independent chains, one process per host core (the reference is not re-entrant)."""
+    """Independent chains, one process per host core (the reference is not re-entrant: global rand(), stateful finder)."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 16)
+
+    cores = os.cpu_count() or 1
+    # each worker holds the slab pair (24 n bytes) and the reference's index (8 n): bound the total
+    per_worker = 48 * len(data) + (64 << 20)
+    cores = max(1, min(cores, int((32 << 30) // per_worker)))
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(data, seconds, 1673551 + i) for i in range(cores)])
     total = sum(d for d, _ in res)
     wall = max(t for _, t in res)
-    return dict(value=total / wall, unit="evals/s", cores=cores, kind="reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libmegalania_ref.so")) else "port",
-                sample=f"{total} SA iterations over {cores} independent chains in {wall:.1f} s")
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libmegalania_ref.so")) else "port"
+    return dict(value=total / wall, unit="evals/s", cores=cores, nproc=os.cpu_count(), cpu=cpu_model(), kind=kind,
+                per_core=total / wall / cores,
+                sample=f"{total} SA iterations over {cores} independent chains (one process per core) in {wall:.1f} s")
 
 
-def pmc_traffic():
-    """HBM traffic of the dominant kernel from a separate `rocprofv3 --pmc` pass (the guide's
-    recipe: counters in their own run), recorded by tools/collect_pmc.sh into profiles/."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def load_pmc(cfg):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_{cfg}.json")
     if not os.path.exists(path):
-        return None, None
+        return None, path
     with open(path) as f:
-        d = json.load(f)
-    return d.get("bytes_per_launch"), d
+        return json.load(f), path
+
+
+def reference_curve(cfg):
+    path = os.path.join(ROOT, "tests", "golden", f"reference_curve_{cfg}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def size_gates(binding, data, K, props, cpu, cfg):
+    """Estimated stream size (18 + perplexity / 16384, main.c:97) of a fresh chain in the default accept mode against
+    the reference path's at (a) equal evaluations and (b) equal steps = reference iterations, both stated."""
+    pts = []
+    curve = reference_curve(cfg)
+    if curve:
+        pts += [(p["iterations"], p["est_bytes"], "tests/golden/reference_curve_%s.json (compiled reference, this input)" % cfg)
+                for p in curve["points"]]
+    if cpu and cpu.get("iterations"):
+        pts.append((cpu["iterations"], cpu["est_bytes_best"], "this run's cpu_baseline sample"))
+    if not pts:
+        return None
+    n = len(data)
+    marks = sorted({-(-it // K) for it, _, _ in pts} | {it for it, _, _ in pts if it <= 4096})
+    sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=n, **props)
+    at, done, evals = {}, 0, 0
+    for m in marks:
+        st = sa.run(m - done)
+        done = m
+        evals += st["evaluations"]
+        at[m] = (18 + st["best_cost"] / 16384, evals)
+    sa.close()
+    out = []
+    for it, ref_bytes, src in pts:
+        s_eq = -(-it // K)
+        row = dict(reference_iterations=it, reference_est_bytes=round(ref_bytes, 1), reference_source=src,
+                   equal_evaluations=dict(gpu_steps=s_eq, gpu_evaluations=at[s_eq][1], gpu_est_bytes=round(at[s_eq][0], 1),
+                                          gpu_le_reference=at[s_eq][0] <= ref_bytes))
+        if it in at:
+            row["equal_steps"] = dict(gpu_steps=it, gpu_evaluations=at[it][1], gpu_est_bytes=round(at[it][0], 1),
+                                      gpu_le_reference=at[it][0] <= ref_bytes)
+        out.append(row)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="c2")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default=None)
     ap.add_argument("--size", type=int, default=0, help="override the input size (bytes)")
     ap.add_argument("--neighbours", type=int, default=0)
+    ap.add_argument("--prepare-steps", type=int, default=-1, help="search steps of the set-up phase (default: per config)")
+    ap.add_argument("--accept", default="auto", choices=["auto", "single", "bulk"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the young-slab rate and the size gates")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        # rehearsal on a one-GPU box: MGL_BENCH_BACKEND=gloo MGL_BENCH_SHARE_GPU=1 runs the same code
-        # path with every rank on GPU 0 and the exchange over gloo (RCCL refuses two ranks per device)
+        # rehearsal on a one-GPU box: MGL_BENCH_BACKEND=gloo MGL_BENCH_SHARE_GPU=1 runs the same code path with every
+        # rank on GPU 0 and the exchange over gloo (RCCL refuses two ranks per device)
         backend = os.environ.get("MGL_BENCH_BACKEND", "nccl")
         if os.environ.get("MGL_BENCH_SHARE_GPU"):
             local_rank = 0
@@ -133,6 +215,7 @@ def main():
             dist.init_process_group(backend)
         coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     n_gpus = world if world > 1 else 1
+    cfg = args.config or ("c3" if n_gpus == 1 else "c4")
 
     from megalania_amd import binding, build as _build, corpus, multi_gpu
 
@@ -141,14 +224,18 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    data, desc = corpus.config_input(args.config, args.size or None)
+    data, desc = corpus.config_input(cfg, args.size or None)
     n = len(data)
-    K = args.neighbours or {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}[args.config]
-    # c5 (ELF-shaped): inside long zero runs a top-K query has > 10^6 candidates in the reference
-    # (SURVEY 3.3); the bench caps the bucket scan at the 4096 nearest hits and says so.
-    props = dict(pb=2, max_bucket_scan=4096) if args.config == "c5" else {}
+    K = args.neighbours or DEFAULT_K[cfg]
+    # c5 (ELF-shaped): inside long zero runs a top-K query has > 10^6 candidates in the reference; the
+    # bench caps the bucket scan at the 4096 nearest hits and says so.
+    props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
+    prepare = args.prepare_steps if args.prepare_steps >= 0 else DEFAULT_PREPARE[cfg]
     sa = binding.SA(data, neighbours_per_step=K, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=n,
-                    device=local_rank, timing=True, **props)
+                    device=local_rank, timing=True, accept=args.accept, **props)
+    comm = None
+    if dist is not None and backend == "nccl":
+        comm = multi_gpu.make_comm(dist, rank, world, local_rank)  # the C library's own RCCL communicator
 
     def sync():
         if dist is not None:
@@ -156,13 +243,18 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    t_prep = time.perf_counter()
+    prep = sa.run(prepare) if prepare else None
+    t_prep = time.perf_counter() - t_prep
     sa.run(args.warmup)
     sync()
     t0 = time.perf_counter()
     st = sa.run(args.steps)
     if dist is not None:
-        import torch
-        multi_gpu.exchange_best(sa, dist, device=coll_device)
+        if comm is not None:
+            multi_gpu.exchange_best_native(sa, comm)
+        else:
+            multi_gpu.exchange_best(sa, dist, device=coll_device)
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -176,14 +268,41 @@ def main():
         elapsed, evals, walked = float(tmax[0]), float(t[1]), float(t[2])
 
     if rank == 0:
-        # dominant kernel: k_neighbours.  Algorithmic bytes per evaluation:
-        # B_eval = N + 12 * P  (every input byte once + one 12-byte packet record per packet)
         P = st["packets"]
-        b_eval = n + 12 * P
+        b_eval = n + 12 * P  # every input byte once + one 12-byte packet record per packet of the parse
         launches = max(1, st["neighbour_launches"])
-        avg_ms = st["gpu_ms_neighbours"] / launches
-        evals_per_launch = st["evaluations"] / max(1, st["steps"])
-        achieved = evals_per_launch * b_eval / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        nbr_ms = st["gpu_ms_neighbours"] / launches  # all neighbour kernels of a step, HIP events on the library's streams
+        evals_per_step = st["evaluations"] / max(1, st["steps"])
+        pmc, pmc_path = load_pmc(cfg)
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "k_neighbours2<PICK> + k_neighbours2<REST> + k_sim (pick, window walk, chain re-simulation: the "
+                          "incremental neighbour evaluation; the step's other launches are the decision and the accept path)",
+                "avg_launch_ms": nbr_ms, "launches_timed": launches,
+                "algorithmic_equiv_gbs": evals_per_step * b_eval / (nbr_ms * 1e-3) / 1e9 if nbr_ms > 0 else None,
+                "algorithmic_note": "evaluations/step x (N + 12 P) / time: what a streaming evaluator would move; the incremental "
+                                    "kernels price only the changed window, so this is not a fraction of anything",
+                "b_eval_bytes": b_eval, "packets_on_walk": P, "packets_walked_per_eval": walked / max(1.0, evals)}
+        if pmc:
+            ks = pmc["kernels"]
+            dom = {k: v for k, v in ks.items() if any(k.startswith(d) for d in DOMINANT)}
+            raw = sum(v.get("hbm_bytes_raw_per_launch", 0.0) * v["launches_per_step"] for v in dom.values())
+            upper = sum(v.get("hbm_bytes_upper_per_launch", 0.0) * v["launches_per_step"] for v in dom.values())
+            prof_us = sum(v["us_per_step"] for v in dom.values())
+            if upper and nbr_ms > 0:
+                roof["traffic"] = upper
+                roof["traffic_raw"] = raw
+                roof["achieved"] = upper / (nbr_ms * 1e-3) / 1e9
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+                roof["frac_raw_counters"] = raw / (nbr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+            roof["profile_us_per_step"] = prof_us
+            roof["limiter"] = {"kind": "latency / issue (dependent L2 + LDS accesses at 3-16 wavefronts per CU), not HBM",
+                               "per_kernel": {k: {c: v[c] for c in ("avg_us", "launches_per_step", "vgpr", "lds", "SQ_WAVES", "SQ_WAVE_CYCLES",
+                                                                    "SQ_BUSY_CYCLES", "wait_any_frac", "issue_stall_frac", "SQ_INSTS_VALU",
+                                                                    "SQ_INSTS_SALU", "hbm_gbs_upper") if c in v} for k, v in dom.items()}}
+        else:
+            roof["traffic_source"] = f"missing: {os.path.relpath(pmc_path, ROOT)} (tools/collect_roofline.sh {cfg})"
+        lcpb = f"{props.get('lc', 0)}/{props.get('lp', 0)}/{props.get('pb', 0)}"
         out = {
             "metric": "SA neighbour-cost evals/s",
             "value": evals / elapsed,
@@ -197,49 +316,74 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"{args.config}: {desc}, {n} B, {K} neighbours/step, top-K 20, "
-                                   f"lc/lp/pb={props.get('lc', 0)}/{props.get('lp', 0)}/{props.get('pb', 0)}"
-                                   + (f", bucket scan capped at {props['max_bucket_scan']}" if props.get("max_bucket_scan") else ""),
-                       "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_neighbours2<PICK> + k_neighbours2<REST> + k_sim (pick, window walk and re-simulation of the incremental neighbour evaluation; + second pass)", "avg_launch_ms": avg_ms,
-                         "launches_timed": launches,
-                         "note": "achieved = evaluations/launch x (N + 12 P) / launch time: algorithmic bytes of the "
-                                 "metric's unit (one exact whole-parse cost); the kernel prices only the changed window",
-                         "b_eval_bytes": b_eval, "packets_on_walk": P,
-                         "packets_walked_per_eval": walked / max(1.0, evals)},
+            "config": {"workload": f"{cfg}: {desc}, {n} B, {K} neighbours/step, top-K 20, lc/lp/pb={lcpb}"
+                                   + (f", bucket scan capped at {props['max_bucket_scan']}" if props.get("max_bucket_scan") else "")
+                                   + f"; slab state: after {prepare} search steps from the all-literal slab (accept mode {args.accept})",
+                       "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"
+                                   + (", best-slab exchange inside the timed region" if n_gpus > 1 else "")},
+            "roofline": roof,
             "final": {"current_cost": st["current_cost"], "best_cost": st["best_cost"],
                       "est_bytes_best": 18 + st["best_cost"] / 16384, "accepted": st["accepted"],
+                      "bulk_steps_timed": st["bulk_steps"], "improving_neighbours": st["improving_neighbours"],
+                      "dropped_neighbours": st["dropped_neighbours"],
                       "gpu_ms_apply_avg": st["gpu_ms_rebuild"] / launches,
                       "gpu_ms_total": st["gpu_ms_total"], "full_rebuilds": st["full_rebuilds"],
                       "fallback_neighbours": st["fallback_neighbours"],
                       "second_pass_neighbours": st["second_pass_neighbours"]},
         }
+        if prep:
+            out["prepare"] = {"steps": prep["steps"], "seconds": t_prep, "evaluations": prep["evaluations"], "bulk_steps": prep["bulk_steps"],
+                              "moves_accepted": prep["accepted"], "est_bytes_best": 18 + prep["best_cost"] / 16384,
+                              "evals_per_s": prep["evaluations"] / t_prep if t_prep > 0 else None}
+        gates = {}
         if n <= (16 << 20):
-            # correctness gates reported with the number, after the timed region: the best slab's
-            # cost re-derived by the device's independent full walk, and its stream through liblzma
+            # correctness gates reported with the number, after the timed region: the best slab's cost
+            # re-derived by the device's independent full walk, and its stream through liblzma
             import lzma
             best, best_cost = sa.best()
-            lcpb = {k: props[k] for k in ("lc", "lp", "pb") if k in props}
-            stream = binding.emit_stream(data, best, **lcpb)
+            lc = {k: props[k] for k in ("lc", "lp", "pb") if k in props}
+            stream = binding.emit_stream(data, best, **lc)
             try:
                 ok = lzma.decompress(stream, format=lzma.FORMAT_ALONE) == bytes(data)
             except lzma.LZMAError:
                 ok = False
-            out["gates"] = {"best_cost_equals_full_walk": sa.cost_slab(best)["total"] == best_cost,
-                            "lzma_roundtrip": ok, "stream_bytes": len(stream)}
-        traffic, src = pmc_traffic()
-        if traffic is not None and args.config == "c2":
-            out["roofline"]["traffic"] = traffic
-            out["roofline"]["traffic_source"] = src
+            gates.update(best_cost_equals_full_walk=sa.cost_slab(best, want_cum=False)["total"] == best_cost,
+                         lzma_roundtrip=ok, stream_bytes=len(stream))
+        sa.close()
         if n_gpus == 1 and not args.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import build_oracle
+            build_oracle.build_oracle()
             out["cpu_baseline"] = cpu_baseline(data, args.cpu_seconds)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(data, min(args.cpu_seconds, 8.0))
+            out["vs_cpu_reference_1_thread"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
+        if n_gpus == 1 and not args.no_secondary:
+            # the rate on the young slab (what round 1 reported) and the size comparison with the reference path
+            y = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=n, timing=True, accept="single", **props)
+            y.run(5)
+            t1 = time.perf_counter()
+            ys = y.run(20)
+            t1 = time.perf_counter() - t1
+            y.close()
+            out["young_slab"] = {"evals_per_s": ys["evaluations"] / t1, "ms_per_step": t1 / 20 * 1e3,
+                                 "note": "single steps 5..25 from the all-literal slab (99 % literals: the state round 1's line was taken in)"}
+            sg = size_gates(binding, data, K, props, out.get("cpu_baseline"), cfg)
+            if sg:
+                gates["size_vs_reference"] = sg
+            if cfg != "c2":
+                c2, _ = corpus.config_input("c2")
+                sg2 = size_gates(binding, c2, DEFAULT_K["c2"], {}, None, "c2")
+                if sg2:
+                    gates["size_vs_reference_c2"] = sg2
+        if gates:
+            out["gates"] = gates
         print(json.dumps(out), flush=True)
-    sa.close()
+    else:
+        sa.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

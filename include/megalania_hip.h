@@ -161,6 +161,27 @@ int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, size_t* count)
 /* Adopt a best slab found elsewhere (another chain / GPU): replaces best slab and best cost.
  * `perplexity` must be the slab's exact cost (it is re-derived on the device and checked). */
 int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t perplexity);
+/* ---- chains on several GPUs (no reference counterpart: the reference is one process; main.c:75-77 is what
+ * an exchange feeds).  One chain per GPU / process; mgl_comm wraps one RCCL communicator (librccl is loaded on
+ * first use).  Rank 0 calls mgl_comm_unique_id and hands the 128 bytes to the others by any means (a file, a
+ * launcher's store); every rank then calls mgl_comm_init on its device. */
+typedef struct mgl_comm mgl_comm;
+int mgl_comm_unique_id(uint8_t id_out[128]);
+int mgl_comm_init(mgl_comm** comm_out, const uint8_t id[128], int rank, int world, int device);
+void mgl_comm_destroy(mgl_comm* comm);
+int mgl_comm_rank(const mgl_comm* comm);
+int mgl_comm_world(const mgl_comm* comm);
+/* One exchange: a single 8-byte ncclAllReduce(min) of (best_cost << 8 | rank), then ncclBroadcast of the
+ * winner's best slab in its packed 8-byte device form, HBM to HBM over xGMI; chains whose own best is worse
+ * adopt it as packets_best (mgl_sa_begin_epoch(.., from_best) continues from it and verifies it first).
+ * winner_rank / winner_cost (nullable) receive the outcome; cost 0 = no chain has a best slab yet.
+ * Collective: every rank of the communicator must call it. */
+int mgl_sa_exchange_best(mgl_sa* sa, mgl_comm* comm, int* winner_rank, uint64_t* winner_cost);
+/* The same hand-over through host memory in the packed device form (dist | len << 32 | type << 48, 8 bytes
+ * per position), for transports other than RCCL.  Adopting does not verify; see mgl_sa_exchange_best. */
+int mgl_sa_best_packed(mgl_sa* sa, uint64_t* packed_out, uint64_t* perplexity_out);
+int mgl_sa_adopt_best_packed(mgl_sa* sa, const uint64_t* packed, uint64_t perplexity);
+
 /* Run `steps` SA steps, each costing cfg.neighbours_per_step neighbours.  Entirely
  * device-resident; the call returns after the last kernel has completed. */
 int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats);

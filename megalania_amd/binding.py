@@ -33,6 +33,8 @@ HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
     "mgl_sa_set_slab", "mgl_sa_seed_greedy", "mgl_sa_set_temperature", "mgl_sa_set_accept_mode", "mgl_sa_step_modes", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
     "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump", "mgl_debug_set",
+    "mgl_comm_unique_id", "mgl_comm_init", "mgl_comm_destroy", "mgl_comm_rank", "mgl_comm_world", "mgl_sa_exchange_best",
+    "mgl_sa_best_packed", "mgl_sa_adopt_best_packed",
 ]
 HOST_SYMBOLS = [
     "mgl_lzma_state_init", "mgl_lzma_state_free", "mgl_lzma_encode_packet", "mgl_lzma_encode_header",
@@ -111,6 +113,14 @@ def hip_lib():
         L.mgl_neighbours.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.mgl_debug_dump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mgl_debug_set.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.mgl_comm_unique_id.argtypes = [C.c_void_p]
+        L.mgl_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mgl_comm_destroy.argtypes = [C.c_void_p]
+        L.mgl_comm_rank.argtypes = [C.c_void_p]
+        L.mgl_comm_world.argtypes = [C.c_void_p]
+        L.mgl_sa_exchange_best.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+        L.mgl_sa_best_packed.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.mgl_sa_adopt_best_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.mgl_rng_draw_at.restype = C.c_uint32
         L.mgl_rng_draw_at.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         _hip = L
@@ -223,6 +233,29 @@ class SA:
         slab = np.ascontiguousarray(slab, dtype=PACKET)
         self._chk(self.L.mgl_sa_set_best(self.h, _ptr(slab), perplexity))
 
+    def best_packed(self):
+        """packets_best in the packed device form (u64 per position) and its cost"""
+        out = np.zeros(self.n, dtype=np.uint64)
+        cost = C.c_uint64(0)
+        self._chk(self.L.mgl_sa_best_packed(self.h, _ptr(out), C.byref(cost)))
+        return out, cost.value
+
+    def best_cost(self) -> int:
+        cost = C.c_uint64(0)
+        self._chk(self.L.mgl_sa_best_packed(self.h, None, C.byref(cost)))
+        return cost.value
+
+    def adopt_best_packed(self, packed, perplexity: int):
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        assert len(packed) == self.n
+        self._chk(self.L.mgl_sa_adopt_best_packed(self.h, _ptr(packed), perplexity))
+
+    def exchange_best(self, comm: "Comm"):
+        """collective over the communicator's ranks (RCCL); returns (winner rank, winner cost)"""
+        w, c = C.c_int(-1), C.c_uint64(0)
+        self._chk(self.L.mgl_sa_exchange_best(self.h, comm.h, C.byref(w), C.byref(c)))
+        return w.value, c.value
+
     def run(self, steps: int) -> dict:
         st = Stats()
         self._chk(self.L.mgl_sa_run(self.h, steps, C.byref(st)))
@@ -285,3 +318,31 @@ class SA:
         diffs = np.zeros((self.K, diff_cap), dtype=DIFF) if want_diffs else None
         self._chk(self.L.mgl_neighbours(self.h, global_step, _ptr(costs), _ptr(diffs), _ptr(nd), diff_cap))
         return costs, nd, diffs
+
+
+class Comm:
+    """One RCCL communicator behind the C ABI (mgl_comm_*): rank 0 makes the id, every rank joins."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        L = hip_lib()
+        buf = (C.c_uint8 * 128)()
+        if L.mgl_comm_unique_id(buf) != 0:
+            raise MglError(L.mgl_last_error().decode())
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int):
+        self.L = hip_lib()
+        assert len(uid) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self.h = C.c_void_p()
+        if self.L.mgl_comm_init(C.byref(self.h), buf, rank, world, device) != 0:
+            raise MglError(self.L.mgl_last_error().decode())
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mgl_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close

@@ -116,8 +116,10 @@ struct mgl_sa {
 	int accept_mode = MGL_ACCEPT_AUTO;
 	uint32_t bulk_threshold = 0;   /* improving neighbours per step above which a bulk step pays */
 	bool bulk_now = true;          /* AUTO: what the next block of steps runs as */
+	uint64_t bulk_hold = 0;        /* AUTO: single steps left before bulk steps are tried again (their windows were too long) */
 	BulkBuf bulk;
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
+	bool best_unverified = false;  /* packets_best came from another chain: checked when an epoch starts from it */
 };
 
 static uint64_t ceil_sqrt_u64(uint64_t x)
@@ -783,6 +785,19 @@ extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 		HIPCHK(hipGetLastError());
 	}
 	if ((rc = rebuild_base(sa, 0))) return rc;
+	if (from_best && sa->best_unverified) {
+		/* a slab adopted from another chain is checked here, where it first matters: every packet against
+		 * the input, and the total against the cost it came with */
+		if ((rc = launch_validate(sa))) return rc;
+		Control v;
+		if ((rc = read_ctl(sa, sa->base, &v))) return rc;
+		if (v.error_flags || v.rebuild_cost != v.best_cost) {
+			v.error_flags = 0;
+			(void)write_ctl(sa, sa->base, &v);
+			return fail(MGL_EINVAL, "mgl_sa_begin_epoch: the adopted best slab is not a valid parse of the input at the cost it came with");
+		}
+		sa->best_unverified = false;
+	}
 	/* the base now is the best (or the literal) slab's: keep it for the next epoch */
 	if (snaps && (rc = launch_snapshot(sa, from_best ? sa->snap_best : sa->snap_lit, from_best ? 1u : 0u, 0, 0))) return rc;
 	HIPCHK(hipStreamSynchronize(sa->stream));
@@ -851,7 +866,7 @@ extern "C" int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_thresh
 	if (mode == MGL_ACCEPT_BULK && !(sa->incremental && sa->parallel_build)) return fail(MGL_EINVAL, "mgl_sa_set_accept_mode: bulk steps need the incremental engine and its parallel builder");
 	sa->accept_mode = mode;
 	if (bulk_threshold) sa->bulk_threshold = bulk_threshold;
-	sa->bulk_now = true;
+	sa->bulk_now = true; sa->bulk_hold = 0;
 	return MGL_OK;
 }
 extern "C" int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, size_t* count)
@@ -860,6 +875,22 @@ extern "C" int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, siz
 	*count = sa->mode_log.size();
 	if (modes_out) memcpy(modes_out, sa->mode_log.data(), cap < sa->mode_log.size() ? cap : sa->mode_log.size());
 	return MGL_OK;
+}
+
+/* MGL_ACCEPT_AUTO, after a block of steps, from device counters only (reproducible): bulk steps pay while a
+ * step offers many improving neighbours AND their windows are short enough for several to be taken at once.
+ * From the all-literal slab nothing resets the rep distances, so every window runs to the end of the file
+ * and a bulk step takes one move like a single step, at three times the price: then single steps for a while. */
+static void auto_decide(mgl_sa* sa, bool was_bulk, uint64_t block, uint64_t improving, uint64_t taken)
+{
+	const bool many = improving >= (uint64_t)sa->bulk_threshold * block;
+	if (was_bulk) {
+		if (taken < 4u * block) { sa->bulk_now = false; sa->bulk_hold = 48; }
+		else sa->bulk_now = many;
+		return;
+	}
+	sa->bulk_hold = sa->bulk_hold > block ? sa->bulk_hold - block : 0;
+	sa->bulk_now = many && sa->bulk_hold == 0;
 }
 
 static DecideArgs decide_args(const mgl_sa* sa)
@@ -908,14 +939,15 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	const DecideArgs dargs = decide_args(sa);
 	const int mode = (sa->incremental && sa->parallel_build) ? sa->accept_mode : MGL_ACCEPT_SINGLE; /* bulk steps rebuild with the parallel builder */
 	sa->mode_log.clear();
-	uint64_t imp_seen = before.imp_cands, last_block = 0;
+	uint64_t imp_seen = before.imp_cands, acc_seen = before.accepted, last_block = 0;
+	bool last_bulk = false;
 	HIPCHK(hipEventRecord(sa->ev_begin, sa->stream));
 	for (uint64_t s = 0; s < steps;) {
 		const bool bulk = mode == MGL_ACCEPT_BULK || (mode == MGL_ACCEPT_AUTO && sa->bulk_now);
 		/* AUTO looks at the device counters between blocks of steps (one small read-back per block) */
 		uint64_t block = steps - s;
 		if (mode == MGL_ACCEPT_AUTO) { const uint64_t b = bulk ? 4u : 16u; block = block < b ? block : b; }
-		last_block = block;
+		last_block = block; last_bulk = bulk;
 		for (uint64_t e = s + block; s < e; s++) {
 			const bool t = s < timed_steps;
 			sa->mode_log.push_back(bulk ? 1 : 0);
@@ -946,15 +978,15 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			Control now;
 			if ((rc = read_ctl(sa, sa->base, &now))) return rc;
 			if (now.error_flags) break;
-			sa->bulk_now = (now.imp_cands - imp_seen) >= (uint64_t)sa->bulk_threshold * block;
-			imp_seen = now.imp_cands;
+			auto_decide(sa, bulk, block, now.imp_cands - imp_seen, now.accepted - acc_seen);
+			imp_seen = now.imp_cands; acc_seen = now.accepted;
 		}
 	}
 	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &after))) return rc;
 	if (mode == MGL_ACCEPT_AUTO && last_block) /* the last block decides how the next call starts */
-		sa->bulk_now = (after.imp_cands - imp_seen) >= (uint64_t)sa->bulk_threshold * last_block;
+		auto_decide(sa, last_bulk, last_block, after.imp_cands - imp_seen, after.accepted - acc_seen);
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
 		stats->steps = after.gstep - before.gstep;
@@ -1218,3 +1250,5 @@ extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
 	}
 	return fail(MGL_EINVAL, "mgl_debug_set: unknown key");
 }
+
+#include "mgl_exchange.inc"

@@ -28,7 +28,7 @@ static void usage(const char* argv0)
 	        "usage: %s [--neighbours K] [--epochs E] [--phases P] [--steps S] [--seed N]\n"
 	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M]\n"
 	        "          [-o out.lzma] [--save-slab file] [--load-slab file] [--greedy-seed C] [--temperature B]\n"
-	        "          [--accept auto|single|bulk] filename\n"
+	        "          [--accept auto|single|bulk] [--chains N --rank R --comm-file PATH] filename\n"
 	        "  -o           write the stream to a file instead of stdout\n"
 	        "  --save-slab  after every epoch, write the best packet slab (resumable checkpoint)\n"
 	        "  --load-slab  start from a slab written by --save-slab (same input, same lc/lp/pb)\n"
@@ -36,6 +36,10 @@ static void usage(const char* argv0)
 	        "               parse instead (longest of the C nearest candidates per position; e.g. 256)\n"
 	        "  --temperature B  Metropolis accept rule instead of the reference's: B = e-folding slack in output\n"
 	        "               bytes at the start of an epoch, cooled linearly to 0 (e.g. 2; 0 = reference rule)\n"
+	        "  --chains N --rank R --comm-file PATH  one of N independent chains, one process per GPU (device = R unless\n"
+	        "               --device says otherwise): after every epoch the chains exchange their best slab over RCCL\n"
+	        "               (8-byte all-reduce + one broadcast); rank 0 creates PATH (the communicator id) and writes the\n"
+	        "               stream, the others wait for PATH\n"
 	        "  --accept     what a step of K neighbours takes: the best acceptable one (single), every one that is\n"
 	        "               the best of its own window (bulk), or whichever pays (auto, default)\n", argv0);
 }
@@ -55,6 +59,8 @@ int main(int argc, char** argv)
 	uint32_t greedy = 0;
 	double temperature_bytes = 0;
 	int accept_mode = MGL_ACCEPT_AUTO;
+	int chains = 1, rank = 0, device_given = 0;
+	const char* comm_path = NULL;
 	for (int i = 1; i < argc; i++) {
 		const char* a = argv[i];
 		const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -68,7 +74,10 @@ int main(int argc, char** argv)
 		else if (!strcmp(a, "--lc")) props.lc = (uint8_t)strtoul(v, NULL, 0);
 		else if (!strcmp(a, "--lp")) props.lp = (uint8_t)strtoul(v, NULL, 0);
 		else if (!strcmp(a, "--pb")) props.pb = (uint8_t)strtoul(v, NULL, 0);
-		else if (!strcmp(a, "--device")) cfg.device = (int32_t)strtol(v, NULL, 0);
+		else if (!strcmp(a, "--device")) { cfg.device = (int32_t)strtol(v, NULL, 0); device_given = 1; }
+		else if (!strcmp(a, "--chains")) chains = (int)strtol(v, NULL, 0);
+		else if (!strcmp(a, "--rank")) rank = (int)strtol(v, NULL, 0);
+		else if (!strcmp(a, "--comm-file")) comm_path = v;
 		else if (!strcmp(a, "--max-scan")) cfg.max_bucket_scan = (uint32_t)strtoul(v, NULL, 0);
 		else if (!strcmp(a, "-o")) out_path = v;
 		else if (!strcmp(a, "--save-slab")) save_path = v;
@@ -85,6 +94,12 @@ int main(int argc, char** argv)
 		i++;
 	}
 	if (!filename) { usage(argv[0]); return -1; }
+	if (chains < 1 || rank < 0 || rank >= chains || (chains > 1 && !comm_path)) { usage(argv[0]); return -1; }
+	if (chains > 1) {
+		if (!device_given) cfg.device = rank;
+		/* distinct, reproducible RNG stream per chain (the same rule as megalania_amd/multi_gpu.py:chain_seed) */
+		if (rank) cfg.seed ^= 0x9E3779B97F4A7C15ull * (uint64_t)(rank + 1);
+	}
 
 	int fd = open(filename, O_RDONLY);
 	if (fd < 0) { fprintf(stderr, "Error: could not open %s\n", filename); return -1; }
@@ -106,6 +121,25 @@ int main(int argc, char** argv)
 	if (temperature_bytes > 0 && mgl_sa_set_temperature(sa, (uint64_t)(temperature_bytes * 16384.0)) != MGL_OK) {
 		fprintf(stderr, "Error: %s\n", mgl_last_error());
 		return -1;
+	}
+	mgl_comm* comm = NULL;
+	if (comm_path) { /* also with --chains 1: the same code path on a one-GPU box */
+		uint8_t uid[128];
+		if (rank == 0) {
+			char tmp[4096];
+			snprintf(tmp, sizeof tmp, "%s.tmp", comm_path);
+			FILE* f = fopen(tmp, "wb");
+			if (mgl_comm_unique_id(uid) != MGL_OK || !f || fwrite(uid, 128, 1, f) != 1 || fclose(f) != 0 || rename(tmp, comm_path) != 0) {
+				fprintf(stderr, "Error: could not publish the communicator id in %s: %s\n", comm_path, mgl_last_error());
+				return -1;
+			}
+		} else {
+			FILE* f = NULL;
+			for (int tries = 0; tries < 1200 && !(f = fopen(comm_path, "rb")); tries++) usleep(100000);
+			if (!f || fread(uid, 128, 1, f) != 1) { fprintf(stderr, "Error: no communicator id in %s\n", comm_path); return -1; }
+			fclose(f);
+		}
+		if (mgl_comm_init(&comm, uid, rank, chains, cfg.device) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 	}
 	if (mgl_sa_set_accept_mode(sa, accept_mode, 0) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
@@ -139,6 +173,12 @@ int main(int argc, char** argv)
 			fprintf(stderr, "current file size: %f\tbest: %f\tstep: %u\tepoch: %04u\t%.0f evals/s\n",
 			        18 + st.current_cost / 16384.f, 18 + st.best_cost / 16384.f, phase + 1, epoch,
 			        st.gpu_ms_total > 0 ? st.evaluations / (st.gpu_ms_total * 1e-3) : 0.0);
+			if (comm) {
+				int winner = -1;
+				uint64_t wcost = 0;
+				if (mgl_sa_exchange_best(sa, comm, &winner, &wcost) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+				fprintf(stderr, "exchange: chain %d holds the best slab, %f bytes\n", winner, 18 + wcost / 16384.f);
+			}
 			if (save_path && st.best_cost != 0) {
 				uint64_t hdr[2] = { file_size, 0 };
 				if (mgl_sa_best(sa, packets_best, &hdr[1]) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
@@ -157,7 +197,9 @@ int main(int argc, char** argv)
 		fprintf(stderr, "Error: could not fetch the best slab: %s\n", mgl_last_error());
 		return -1;
 	}
+	mgl_comm_destroy(comm);
 	mgl_sa_destroy(sa);
+	if (rank != 0) return 0; /* every chain holds the common best slab after the last exchange; rank 0 writes it */
 
 	FILE* out = stdout;
 	if (out_path && (out = fopen(out_path, "wb")) == NULL) { fprintf(stderr, "Error: could not open %s\n", out_path); return -1; }

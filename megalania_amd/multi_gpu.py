@@ -24,12 +24,14 @@ def pack_key(best_cost: int, rank: int) -> int:
 
 
 def exchange_best(chain, dist, device=None):
-    """One exchange epoch.  `chain` offers best() -> (slab, cost) and set_best(slab, cost);
-    `dist` is torch.distributed (already initialised).  Returns (winner_rank, winner_cost)."""
+    """One exchange epoch over torch.distributed (any backend; the CPU tests use gloo).  `chain` offers
+    best_cost(), best_packed() -> (u64 words, cost) and adopt_best_packed(words, cost).  The slab travels in
+    its packed device form, 8 bytes per position.  Returns (winner_rank, winner_cost).
+    On GPUs the native path is `exchange_best_native` (RCCL from the C library, HBM to HBM)."""
     import torch
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    slab, cost = chain.best()
+    cost = chain.best_cost()
     key = torch.tensor([pack_key(cost, rank)], dtype=torch.int64, device=device)
     dist.all_reduce(key, op=dist.ReduceOp.MIN)
     k = int(key.item())
@@ -38,18 +40,31 @@ def exchange_best(chain, dist, device=None):
         return winner, 0  # nobody has a best slab yet
     if world == 1:
         return winner, wcost
-    # winner's slab, field-wise as int32 words (type, dist, len): 12 bytes per position
     if rank == winner:
-        words = np.stack([slab["type"].astype(np.int64), slab["dist"].astype(np.int64), slab["len"].astype(np.int64)])
-        buf = torch.from_numpy(words.astype(np.int64))
+        words, _ = chain.best_packed()
+        buf = torch.from_numpy(words.view(np.int64).copy())
     else:
-        buf = torch.empty((3, len(slab)), dtype=torch.int64)
+        buf = torch.empty(chain.n, dtype=torch.int64)
     if device is not None:
         buf = buf.to(device)
     dist.broadcast(buf, src=winner)
     if rank != winner and (cost == 0 or wcost < cost):
-        words = buf.cpu().numpy()
-        new = np.zeros(len(slab), dtype=slab.dtype)
-        new["type"], new["dist"], new["len"] = words[0], words[1], words[2]
-        chain.set_best(new, wcost)
+        chain.adopt_best_packed(buf.cpu().numpy().view(np.uint64), wcost)
     return winner, wcost
+
+
+def make_comm(dist, rank: int, world: int, device: int):
+    """An RCCL communicator of the C library for this process group: rank 0 draws the id, torch.distributed
+    (whatever its backend) only carries those 128 bytes."""
+    from . import binding
+
+    box = [binding.Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return binding.Comm(box[0], rank, world, device)
+
+
+def exchange_best_native(chain, comm):
+    """The north-star exchange, entirely inside the C library: 8-byte ncclAllReduce(min) + ncclBroadcast of
+    the packed slab from the winner's HBM to the others'."""
+    return chain.exchange_best(comm)

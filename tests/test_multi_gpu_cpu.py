@@ -14,17 +14,22 @@ from megalania_amd import binding, multi_gpu
 
 
 class FakeChain:
+    """packed device form: dist | len << 32 | type << 48, one u64 per position"""
+
     def __init__(self, n, cost, fill):
-        self.slab = binding.literal_slab(n)
-        self.slab["dist"][:] = fill
+        self.n = n
+        self.words = np.full(n, (1 << 48) | (1 << 32) | fill, dtype=np.uint64)
         self.cost = cost
         self.adopted = None
 
-    def best(self):
-        return self.slab, self.cost
+    def best_cost(self):
+        return self.cost
 
-    def set_best(self, slab, cost):
-        self.slab, self.cost, self.adopted = slab.copy(), cost, cost
+    def best_packed(self):
+        return self.words, self.cost
+
+    def adopt_best_packed(self, words, cost):
+        self.words, self.cost, self.adopted = words.copy(), cost, cost
 
 
 def _worker(rank, world, port, costs, out):
@@ -33,7 +38,8 @@ def _worker(rank, world, port, costs, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     chain = FakeChain(257, costs[rank], fill=rank + 1)
     winner, wcost = multi_gpu.exchange_best(chain, dist)
-    out.put((rank, winner, wcost, chain.cost, int(chain.slab["dist"][0]), chain.adopted))
+    assert chain.words.dtype == np.uint64 and len(chain.words) == 257 and (chain.words >> np.uint64(32) == (1 << 16) | 1).all()
+    out.put((rank, winner, wcost, chain.cost, int(chain.words[0] & np.uint64(0xFFFFFFFF)), chain.adopted))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -46,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 PROFILE_TAG = "r02"
 DEFAULT_K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}
-DEFAULT_PREPARE = {"c1": 64, "c2": 400, "c3": 700, "c4": 700, "c5": 400}
+PREPARE_CAP = {"c1": 400, "c2": 1500, "c3": 6000, "c4": 1500, "c5": 2000}  # steps; the bulk phase normally ends well before
 DOMINANT = ("k_neighbours2<false, 1>", "k_neighbours2<false, 2>", "k_sim")
 
 
@@ -187,7 +187,9 @@ def main():
     ap.add_argument("--config", default=None)
     ap.add_argument("--size", type=int, default=0, help="override the input size (bytes)")
     ap.add_argument("--neighbours", type=int, default=0)
-    ap.add_argument("--prepare-steps", type=int, default=-1, help="search steps of the set-up phase (default: per config)")
+    ap.add_argument("--prepare-steps", type=int, default=-1,
+                    help="search steps of the set-up phase (default: until the library's bulk phase is over, capped per config and at --prepare-seconds)")
+    ap.add_argument("--prepare-seconds", type=float, default=90.0)
     ap.add_argument("--accept", default="auto", choices=["auto", "single", "bulk"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -230,7 +232,6 @@ def main():
     # c5 (ELF-shaped): inside long zero runs a top-K query has > 10^6 candidates in the reference; the
     # bench caps the bucket scan at the 4096 nearest hits and says so.
     props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
-    prepare = args.prepare_steps if args.prepare_steps >= 0 else DEFAULT_PREPARE[cfg]
     sa = binding.SA(data, neighbours_per_step=K, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=n,
                     device=local_rank, timing=True, accept=args.accept, **props)
     comm = None
@@ -243,8 +244,22 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    # set-up: the chain as a long run has it.  By default: until a whole chunk of steps ran without a bulk step
+    # (the library's AUTO mode has left its bulk phase), every rank for itself
     t_prep = time.perf_counter()
-    prep = sa.run(prepare) if prepare else None
+    prep = None
+    if args.prepare_steps != 0:
+        prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, best_cost=0)
+        cap = args.prepare_steps if args.prepare_steps > 0 else PREPARE_CAP[cfg]
+        chunk = cap if args.prepare_steps > 0 else (64 if n <= (1 << 20) else 128)
+        while prep["steps"] < cap:
+            p = sa.run(min(chunk, cap - prep["steps"]))
+            for k in ("steps", "evaluations", "bulk_steps", "accepted"):
+                prep[k] += p[k]
+            prep["best_cost"] = p["best_cost"]
+            if args.prepare_steps < 0 and (p["bulk_steps"] == 0 or time.perf_counter() - t_prep > args.prepare_seconds):
+                break
+    prepare = prep["steps"] if prep else 0
     t_prep = time.perf_counter() - t_prep
     sa.run(args.warmup)
     sync()

@@ -58,6 +58,8 @@ struct mgl_sa {
 	hipStream_t stream;
 	hipStream_t stream2;     /* second half of a step's neighbours: its kernels fill the other half's tails */
 	hipEvent_t ev_fork, ev_join;
+	hipStream_t stream3 = nullptr;   /* the re-simulation kernels of the split form: beside the second pass, which only needs the walks */
+	hipEvent_t ev_rest[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }, ev_sim = nullptr;
 	uint32_t halves;
 	uint32_t n;
 	mgl_properties props;
@@ -70,6 +72,14 @@ struct mgl_sa {
 	uint16_t* d_bucket_nx;
 	uint32_t* d_quad_pos;
 	uint16_t* d_quad_nx;
+	uint32_t *d_quad_rank = nullptr, *d_quad_run = nullptr;
+	uint32_t* d_xpos[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };  /* exact-length orders D = 2..7; [0] and [2] alias bucket_pos / quad_pos */
+	uint32_t* d_xrank[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	uint32_t* d_xrun[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	uint8_t* d_xnxb[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	uint32_t *d_oct_pos = nullptr, *d_oct_rank = nullptr, *d_oct_run = nullptr;
+	uint32_t *d_hex_pos = nullptr, *d_hex_rank = nullptr, *d_hex_run = nullptr;
+	uint64_t *d_oct_nx8 = nullptr, *d_hex_nx8 = nullptr;
 	uint16_t* d_cost_tbl;
 	BaseMem base, scratch;
 	mgl_pk* d_best;
@@ -98,7 +108,8 @@ struct mgl_sa {
 	uint32_t* d_todo2;
 	uint4* d_pickstate;     /* 2 K: target, RNG position and walk state at the target (first half -> second half) */
 	uint4* d_pickrec;       /* K: picked packet, RNG position, ok flag (first half -> second half of the neighbour evaluation) */
-	bool split_nbr, adaptive; /* adaptive: the device switches between the split and the one-kernel form step by step */
+	bool split_nbr, adaptive; /* adaptive: the device recommends the split or the one-kernel form, the host adopts it block by block */
+	bool form_single = false; /* the form the regular launch runs as right now */
 	uint32_t* d_counts;     /* [0] first-pass overflow count, [1] second-pass overflow count, [2] spill slots used */
 	ApplyBuf ab;
 	uint32_t apply_blocks;
@@ -285,7 +296,7 @@ static int launch_apply(mgl_sa* sa)
 	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
 	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
-	hipLaunchKernelGGL(k_build_end, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->snapshots ? 1 : 0, sa->d_counts, sa->adaptive ? 1 : 0);
+	hipLaunchKernelGGL(k_build_end, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->snapshots ? 1 : 0, sa->d_counts, sa->adaptive ? 1 : 0, sa->form_single ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -302,14 +313,15 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	}
 	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 4 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
-	if (sa->split_nbr) {
-		/* the step's neighbours in two slices on two streams: while the slowest wavefronts of one
-		 * slice's kernel finish, the other slice's kernels keep the CUs busy */
+	const bool split_now = sa->split_nbr && !sa->form_single;
+	if (split_now) {
+		/* the step's neighbours in slices on two streams: while the slowest wavefronts of one slice's kernel finish,
+		 * the other slice's kernels keep the CUs busy.  The re-simulation kernels run on a third stream: the second
+		 * pass below needs the walks, not the re-simulations, and its few long-running wavefronts overlap with them. */
 		const uint32_t slices = (sa->halves >= 2 && K >= 1024) ? sa->halves : 1u;
-		if (slices >= 2) {
-			HIPCHK(hipEventRecord(sa->ev_fork, sa->stream));
-			HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_fork, 0));
-		}
+		HIPCHK(hipEventRecord(sa->ev_fork, sa->stream));
+		if (slices >= 2) HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_fork, 0));
+		HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_fork, 0));
 		for (uint32_t h = 0; h < slices; h++) {
 			const uint32_t j0 = (uint32_t)((uint64_t)K * h / slices), j1 = (uint32_t)((uint64_t)K * (h + 1) / slices);
 			hipStream_t st = (h & 1u) ? sa->stream2 : sa->stream; /* slices alternate between the two streams */
@@ -320,29 +332,32 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), 4096u + sa->per_wave_rest, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
 			                   sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
-			/* the second half's re-simulation, several wavefronts per neighbour */
-			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u, st, sa->ctx, sa->b2, sa->base.ctl,
-			                   sa->nbr, sa->big, j0, j1, sa->d_todo, sa->d_counts);
+			HIPCHK(hipEventRecord(sa->ev_rest[h], st));
+			/* the second half's re-simulation, several wavefronts per neighbour; a neighbour with more touched contexts
+			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
+			HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
+			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
+			                   sa->nbr, sa->big, j0, j1, sa->d_todo2, sa->d_counts + 1);
 		}
-		if (slices >= 2) {
-			HIPCHK(hipEventRecord(sa->ev_join, sa->stream2));
-			HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_join, 0));
-		}
+		HIPCHK(hipEventRecord(sa->ev_sim, sa->stream3));
+		for (uint32_t h = 1; h < slices; h += 2) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_rest[h], 0)); /* the walks of the other stream's slices */
 	}
-	if (!sa->split_nbr || sa->adaptive) { /* whichever form Control::nbr_single names does the work, the other returns at once */
+	if (!sa->split_nbr || sa->form_single) { /* the one-kernel form */
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
 		                   sa->d_prof, sa->big, sa->d_pickrec, 0u, K, sa->d_pickstate);
 	}
 	/* the few whose change lists overflowed LDS (or that need a second top-K pick): the whole
 	 * evaluation in one kernel, lists in global scratch */
-	const uint32_t bigblocks = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* one per neighbour: none is dropped */
+	const uint32_t bigneed = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* a slot per neighbour: none is dropped */
+	const uint32_t bigblocks = bigneed < 1024u ? bigneed : 1024u; /* the kernel strides over its list */
 	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   (unsigned long long*)nullptr, sa->big, sa->split_nbr ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
-	/* and whatever overflowed even that: exact full walk from byte 0 */
+	                   (unsigned long long*)nullptr, sa->big, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
+	/* and whatever overflowed even that: exact full walk from byte 0 (a small grid strides over the list) */
+	if (split_now) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
-	hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
+	hipLaunchKernelGGL(k_neighbours, dim3(blocks < 256u ? blocks : 256u), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
 	                   (const uint32_t*)sa->d_todo2, (const uint32_t*)(sa->d_counts + 1));
 	HIPCHK(hipGetLastError());
@@ -371,6 +386,9 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	(void)hipSetDevice(sa->device);
 	if (sa->stream) (void)hipStreamSynchronize(sa->stream);
 	dfree(sa->d_data); dfree(sa->d_bucket_off); dfree(sa->d_bucket_pos); dfree(sa->d_bucket_nx); dfree(sa->d_quad_pos); dfree(sa->d_quad_nx); dfree(sa->d_cost_tbl);
+	dfree(sa->d_quad_rank); dfree(sa->d_quad_run); dfree(sa->d_oct_pos);
+	for (int i = 0; i < 6; i++) { if (i != 0 && i != 2) { dfree(sa->d_xpos[i]); dfree(sa->d_xrank[i]); dfree(sa->d_xrun[i]); } dfree(sa->d_xnxb[i]); } dfree(sa->d_oct_rank); dfree(sa->d_oct_run);
+	dfree(sa->d_hex_pos); dfree(sa->d_hex_rank); dfree(sa->d_hex_run); dfree(sa->d_oct_nx8); dfree(sa->d_hex_nx8);
 	free_base(sa->base); free_base(sa->scratch);
 	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.win); dfree(sa->nbr.dpos);
@@ -393,6 +411,9 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	if (sa->ev_begin) (void)hipEventDestroy(sa->ev_begin);
 	if (sa->ev_end) (void)hipEventDestroy(sa->ev_end);
 	if (sa->stream2) (void)hipStreamDestroy(sa->stream2);
+	if (sa->stream3) (void)hipStreamDestroy(sa->stream3);
+	for (auto& e : sa->ev_rest) if (e) (void)hipEventDestroy(e);
+	if (sa->ev_sim) (void)hipEventDestroy(sa->ev_sim);
 	if (sa->ev_fork) (void)hipEventDestroy(sa->ev_fork);
 	if (sa->ev_join) (void)hipEventDestroy(sa->ev_join);
 	if (sa->stream) (void)hipStreamDestroy(sa->stream);
@@ -406,6 +427,9 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipStreamCreate(&sa->stream2));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_fork, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_join, hipEventDisableTiming));
+	HIPCHK(hipStreamCreate(&sa->stream3));
+	for (auto& e : sa->ev_rest) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&sa->ev_sim, hipEventDisableTiming));
 	/* measured: + 8 % on the 10 MB input, nothing on the 100 KB one (its kernels are too short to overlap) */
 	sa->halves = getenv("MGL_HALVES") ? (uint32_t)atoi(getenv("MGL_HALVES")) : (n > (1u << 20) ? 2u : 1u);
 	if (sa->halves < 1 || sa->halves > 8) sa->halves = 1;
@@ -428,6 +452,21 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMalloc(&sa->d_bucket_nx, sizeof(uint16_t) * (n ? n : 1)));
 		HIPCHK(hipMalloc(&sa->d_quad_pos, sizeof(uint32_t) * (n ? n : 1)));
 		HIPCHK(hipMalloc(&sa->d_quad_nx, sizeof(uint16_t) * (n ? n : 1)));
+		for (int i = 0; i < 6; i++) {
+			HIPCHK(hipMalloc(&sa->d_xnxb[i], n + 1));
+			HIPCHK(hipMemset(sa->d_xnxb[i], 0, n + 1));
+			if (i == 0 || i == 2) continue;
+			for (uint32_t** a : { &sa->d_xpos[i], &sa->d_xrank[i], &sa->d_xrun[i] }) {
+				HIPCHK(hipMalloc(a, sizeof(uint32_t) * (n + 1)));
+				HIPCHK(hipMemset(*a, 0, sizeof(uint32_t) * (n + 1)));
+			}
+		}
+		for (uint32_t** a : { &sa->d_quad_rank, &sa->d_quad_run, &sa->d_oct_pos, &sa->d_oct_rank, &sa->d_oct_run, &sa->d_hex_pos, &sa->d_hex_rank, &sa->d_hex_run }) {
+			HIPCHK(hipMalloc(a, sizeof(uint32_t) * (n + 1)));
+			HIPCHK(hipMemset(*a, 0, sizeof(uint32_t) * (n + 1)));
+		}
+		HIPCHK(hipMalloc(&sa->d_oct_nx8, sizeof(uint64_t) * (n + 1)));
+		HIPCHK(hipMalloc(&sa->d_hex_nx8, sizeof(uint64_t) * (n + 1)));
 		if (m == 0) HIPCHK(hipMemset(sa->d_bucket_off, 0, sizeof(uint32_t) * 65537));
 		else {
 			const uint32_t nblk = (m + MGL_IX_ITEMS - 1) / MGL_IX_ITEMS;
@@ -458,6 +497,37 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			}
 			hipLaunchKernelGGL(ix_next2, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data,
 			                   (const uint32_t*)sa->d_quad_pos, m, sa->d_quad_nx, 1);
+			/* the eight- and sixteen-byte orders, and for all three deeper orders: rank, run starts, next bytes */
+			sa->d_xpos[0] = sa->d_bucket_pos; sa->d_xpos[2] = sa->d_quad_pos;
+			sa->d_xrank[2] = sa->d_quad_rank; sa->d_xrun[2] = sa->d_quad_run;
+			for (uint32_t D : { 3u, 5u, 6u, 7u, 8u, 16u }) {
+				uint32_t* dst = D == 8 ? sa->d_oct_pos : D == 16 ? sa->d_hex_pos : sa->d_xpos[D - 2];
+				for (int pass = (int)D - 1; pass >= 0; pass--) {
+					/* ping-pong so that the last pass (byte 0) lands in dst */
+					const uint32_t* in = pass == (int)D - 1 ? nullptr : ((pass & 1) ? (const uint32_t*)dst : (const uint32_t*)tmp);
+					uint32_t* out = (pass & 1) ? tmp : dst;
+					hipLaunchKernelGGL(ix_count, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, m, pass, matrix, nblk);
+					hipLaunchKernelGGL(ix_scan, dim3(1), dim3(1024), 0, sa->stream, matrix, 256u * nblk);
+					hipLaunchKernelGGL(ix_scatter, dim3(nblk), dim3(64), 0, sa->stream, (const uint8_t*)sa->d_data, in, out, m, pass,
+					                   (const uint32_t*)matrix, nblk);
+				}
+			}
+			struct { const uint32_t* pos; uint32_t* rank; uint32_t* run; void* nx; uint32_t D, nxbytes; } lv[7] = {
+				{ sa->d_xpos[1], sa->d_xrank[1], sa->d_xrun[1], sa->d_xnxb[1], 3u, 1u },
+				{ sa->d_quad_pos, sa->d_quad_rank, sa->d_quad_run, sa->d_xnxb[2], 4u, 1u },
+				{ sa->d_xpos[3], sa->d_xrank[3], sa->d_xrun[3], sa->d_xnxb[3], 5u, 1u },
+				{ sa->d_xpos[4], sa->d_xrank[4], sa->d_xrun[4], sa->d_xnxb[4], 6u, 1u },
+				{ sa->d_xpos[5], sa->d_xrank[5], sa->d_xrun[5], sa->d_xnxb[5], 7u, 1u },
+				{ sa->d_oct_pos, sa->d_oct_rank, sa->d_oct_run, sa->d_oct_nx8, 8u, 8u },
+				{ sa->d_hex_pos, sa->d_hex_rank, sa->d_hex_run, sa->d_hex_nx8, 16u, 8u } };
+			hipLaunchKernelGGL(ix_next_byte, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data, (const uint32_t*)sa->d_bucket_pos, m, sa->d_xnxb[0], 2u);
+			for (auto& l : lv) {
+				hipLaunchKernelGGL(ix_rank, dim3(m / 256 + 1), dim3(256), 0, sa->stream, l.pos, m, l.rank);
+				if (l.nxbytes == 1) hipLaunchKernelGGL(ix_next_byte, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data, l.pos, m, (uint8_t*)l.nx, l.D);
+				else hipLaunchKernelGGL(ix_next_bytes, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data, l.pos, m, l.nx, l.D, l.nxbytes);
+				hipLaunchKernelGGL(ix_heads, dim3(m / 256 + 1), dim3(256), 0, sa->stream, (const uint8_t*)sa->d_data, l.pos, m, l.D, l.run);
+				hipLaunchKernelGGL(ix_maxscan, dim3(1), dim3(1024), 0, sa->stream, l.run, m);
+			}
 			hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(sa->stream);
 			(void)hipFree(tmp); (void)hipFree(matrix);
 			HIPCHK(e1); HIPCHK(e2);
@@ -468,6 +538,9 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 
 	sa->ctx.data = sa->d_data; sa->ctx.n = (uint32_t)n;
 	sa->ctx.bucket_off = sa->d_bucket_off; sa->ctx.bucket_pos = sa->d_bucket_pos; sa->ctx.bucket_nx = sa->d_bucket_nx; sa->ctx.quad_pos = sa->d_quad_pos; sa->ctx.quad_nx = sa->d_quad_nx;
+	for (int i = 0; i < 6; i++) { sa->ctx.xpos[i] = sa->d_xpos[i]; sa->ctx.xrank[i] = sa->d_xrank[i]; sa->ctx.xrun[i] = sa->d_xrun[i]; sa->ctx.xnxb[i] = sa->d_xnxb[i]; }
+	sa->ctx.oct_pos = sa->d_oct_pos; sa->ctx.oct_rank = sa->d_oct_rank; sa->ctx.oct_run = sa->d_oct_run; sa->ctx.oct_nx8 = sa->d_oct_nx8;
+	sa->ctx.hex_pos = sa->d_hex_pos; sa->ctx.hex_rank = sa->d_hex_rank; sa->ctx.hex_run = sa->d_hex_run; sa->ctx.hex_nx8 = sa->d_hex_nx8;
 	sa->ctx.cost_tbl = sa->d_cost_tbl; sa->ctx.L = L;
 	sa->ctx.dict_limit = sa->cfg.dict_limit; sa->ctx.max_scan = sa->cfg.max_bucket_scan; sa->ctx.top_k = sa->cfg.top_k;
 
@@ -651,12 +724,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMemset(g.sim_hdr, 0xFF, sizeof(uint4) * (size_t)K));
 		}
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
-		if (!sa->split_nbr) { /* one-kernel form only */
-			Control c0;
-			HIPCHK(hipMemcpy(&c0, sa->base.ctl, sizeof c0, hipMemcpyDeviceToHost));
-			c0.nbr_single = 1;
-			HIPCHK(hipMemcpy(sa->base.ctl, &c0, sizeof c0, hipMemcpyHostToDevice));
-		}
+		sa->form_single = !sa->split_nbr; /* one-kernel form only, or the split form until the device recommends otherwise */
 		/* eight pick wavefronts share a cost table per workgroup: 4 KiB + 8 x 9.3 KiB = 78 KiB, two
 		 * workgroups = 16 wavefronts per CU, so the 4 096 neighbours of a c2 step are all resident at
 		 * once (with two per workgroup 14 fit and the last 512 waited for a slot: 127 -> 108 us).
@@ -921,7 +989,7 @@ static int launch_bulk_tail(mgl_sa* sa)
 		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 	}
 	hipLaunchKernelGGL(k_bulk_reset, dim3(1), dim3(64), 0, sa->stream, sa->bulk);
-	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, 0, sa->d_counts, 0);
+	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, 0, sa->d_counts, 0, sa->form_single ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -945,8 +1013,10 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	for (uint64_t s = 0; s < steps;) {
 		const bool bulk = mode == MGL_ACCEPT_BULK || (mode == MGL_ACCEPT_AUTO && sa->bulk_now);
 		/* AUTO looks at the device counters between blocks of steps (one small read-back per block) */
+		/* every block ends with one small read-back: AUTO needs the counters, and the form of the regular launch
+		 * (split / one kernel) follows the device's recommendation from block to block */
 		uint64_t block = steps - s;
-		if (mode == MGL_ACCEPT_AUTO) { const uint64_t b = bulk ? 4u : 16u; block = block < b ? block : b; }
+		{ const uint64_t b = mode == MGL_ACCEPT_AUTO ? (bulk ? 4u : 16u) : 64u; block = block < b ? block : b; }
 		last_block = block; last_bulk = bulk;
 		for (uint64_t e = s + block; s < e; s++) {
 			const bool t = s < timed_steps;
@@ -974,17 +1044,21 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			}
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 		}
-		if (mode == MGL_ACCEPT_AUTO && s < steps) {
+		if (s < steps && (mode == MGL_ACCEPT_AUTO || sa->adaptive)) {
 			Control now;
 			if ((rc = read_ctl(sa, sa->base, &now))) return rc;
 			if (now.error_flags) break;
-			auto_decide(sa, bulk, block, now.imp_cands - imp_seen, now.accepted - acc_seen);
-			imp_seen = now.imp_cands; acc_seen = now.accepted;
+			if (sa->adaptive) sa->form_single = now.nbr_single != 0;
+			if (mode == MGL_ACCEPT_AUTO) {
+				auto_decide(sa, bulk, block, now.imp_cands - imp_seen, now.accepted - acc_seen);
+				imp_seen = now.imp_cands; acc_seen = now.accepted;
+			}
 		}
 	}
 	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &after))) return rc;
+	if (sa->adaptive) sa->form_single = after.nbr_single != 0;
 	if (mode == MGL_ACCEPT_AUTO && last_block) /* the last block decides how the next call starts */
 		auto_decide(sa, last_bulk, last_block, after.imp_cands - imp_seen, after.accepted - acc_seen);
 	if (stats) {

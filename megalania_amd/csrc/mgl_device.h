@@ -32,6 +32,18 @@ struct DevCtx {
 	const uint16_t* bucket_nx;  /* per entry of bucket_pos: data[p + 2] | data[p + 3] << 8 */
 	const uint32_t* quad_pos;   /* the same positions ordered by (data[p..p+3], p): inside a bigram bucket, runs of equal next-two-bytes */
 	const uint16_t* quad_nx;    /* per entry of quad_pos: data[p + 2] << 8 | data[p + 3] (ascending inside a bucket) */
+	/* deeper orders of the same positions (mgl_index.hip): sorted by the first 4 / 8 / 16 bytes, then by position.
+	 * Per order: rank[p] = where position p sits; run[i] = first entry of the run of equal prefixes entry i belongs
+	 * to (so the earlier positions that share p's prefix are exactly entries [run[rank[p]], rank[p])); and the
+	 * bytes that follow the prefix, so that a hit's match length is known up to the next order's prefix without
+	 * touching the input */
+	/* the exact-length sources, D = 2..7 (index D - 2): positions ordered by their first D bytes then by position
+	 * (D = 2: the bigram bucket itself, D = 4: quad_pos), rank / run as above (unused for D = 2: the bucket bounds
+	 * play that part), and byte D of every entry: an entry whose byte D equals the target's belongs to the next
+	 * source, all others match exactly D bytes */
+	const uint32_t* xpos[6]; const uint32_t* xrank[6]; const uint32_t* xrun[6]; const uint8_t* xnxb[6];
+	const uint32_t* oct_pos; const uint32_t* oct_rank; const uint32_t* oct_run; const uint64_t* oct_nx8;    /* bytes 8..15 */
+	const uint32_t* hex_pos; const uint32_t* hex_rank; const uint32_t* hex_run; const uint64_t* hex_nx8;    /* bytes 16..23 */
 	const uint16_t* cost_tbl;   /* 2048 x u16 */
 	mgl_layout L;
 	uint32_t dict_limit;

@@ -125,6 +125,71 @@ __global__ void __launch_bounds__(256) ix_next2(const uint8_t* data, const uint3
 	nx[j] = (uint16_t)(big_endian ? ((a << 8) | b) : (a | (b << 8)));
 }
 
+/* ---- the deeper orders: rank of every position, start of its run of equal prefixes, the bytes behind the prefix */
+__global__ void __launch_bounds__(256) ix_rank(const uint32_t* sorted, uint32_t m, uint32_t* rank)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m) rank[sorted[j]] = j;
+}
+/* nx[j] = the `bytes` (4 or 8) input bytes at sorted[j] + off, little endian (the input is zero padded past its end) */
+__global__ void __launch_bounds__(256) ix_next_bytes(const uint8_t* data, const uint32_t* sorted, uint32_t m, void* nx, uint32_t off, uint32_t bytes)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	const uint8_t* p = data + sorted[j] + off;
+	if (bytes == 4) { uint32_t v; __builtin_memcpy(&v, p, 4); ((uint32_t*)nx)[j] = v; }
+	else { uint64_t v; __builtin_memcpy(&v, p, 8); ((uint64_t*)nx)[j] = v; }
+}
+/* nxb[j] = input byte at sorted[j] + off */
+__global__ void __launch_bounds__(256) ix_next_byte(const uint8_t* data, const uint32_t* sorted, uint32_t m, uint8_t* nxb, uint32_t off)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < m) nxb[j] = data[sorted[j] + off];
+}
+/* run[j] = j where entry j starts a run (its first D bytes differ from entry j - 1's), else 0 ... */
+__global__ void __launch_bounds__(256) ix_heads(const uint8_t* data, const uint32_t* sorted, uint32_t m, uint32_t D, uint32_t* run)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	bool head = j == 0;
+	if (!head) {
+		const uint8_t *a = data + sorted[j], *b = data + sorted[j - 1];
+		for (uint32_t i = 0; i < D; i++) head |= a[i] != b[i];
+	}
+	run[j] = head ? j : 0u;
+}
+/* ... and an inclusive running maximum turns that into "start of my run" (one workgroup, in place) */
+__global__ void __launch_bounds__(1024) ix_maxscan(uint32_t* a, uint32_t count)
+{
+	__shared__ uint32_t wmax[16];
+	__shared__ uint32_t carry_s;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	if (tid == 0) carry_s = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < count; base += 4096) {
+		const uint32_t i0 = base + tid * 4;
+		uint32_t v[4], s = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { v[k] = (i0 + k) < count ? a[i0 + k] : 0u; s = v[k] > s ? v[k] : s; v[k] = s; }
+		uint32_t incl = s;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+			if ((int)lane >= o) incl = t > incl ? t : incl;
+		}
+		if (lane == 63) wmax[wv] = incl;
+		__syncthreads();
+		uint32_t before = carry_s;
+		for (uint32_t w = 0; w < wv; w++) before = wmax[w] > before ? wmax[w] : before;
+		const uint32_t prev = (uint32_t)__shfl_up((int)incl, 1, 64);
+		if (lane > 0) before = prev > before ? prev : before;
+#pragma unroll
+		for (int k = 0; k < 4; k++) if ((i0 + k) < count) a[i0 + k] = v[k] > before ? v[k] : before;
+		__syncthreads();
+		if (tid == 1023) carry_s = incl > before ? incl : before;
+		__syncthreads();
+	}
+}
+
 /* ================================================================== greedy seed
  *
  * The reference starts every search from the all-literal slab (main.c:71).  A packet slab holds

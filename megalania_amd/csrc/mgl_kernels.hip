@@ -242,8 +242,6 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 		}
 		minlen_m = uni(a); minlen_r = uni(b);
 	}
-	const uint32_t hdr_lr_min = hdr_lr0 < hdr_lr1 ? (hdr_lr0 < hdr_lr2 ? (hdr_lr0 < hdr_lr3 ? hdr_lr0 : hdr_lr3) : (hdr_lr2 < hdr_lr3 ? hdr_lr2 : hdr_lr3))
-	                                              : (hdr_lr1 < hdr_lr2 ? (hdr_lr1 < hdr_lr3 ? hdr_lr1 : hdr_lr3) : (hdr_lr2 < hdr_lr3 ? hdr_lr2 : hdr_lr3));
 
 	/* LITERAL and SHORT_REP, packet_enumerator.c:60-66 */
 	{
@@ -270,194 +268,302 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	/* substring_enumerator.c:85-105: nothing at the first and the last byte */
 	if (pos == 0 || pos >= c.n - 1) return;
 	const uint32_t bigram = ((uint32_t)walk_byte_at(w, pos) << 8) | c.data[pos + 1];
-	uint32_t lo = c.bucket_off[bigram], end = c.bucket_off[bigram + 1];
-	uint32_t hi = bucket_lower_bound(c.bucket_pos, lo, end, pos, lane); /* hits are < pos */
+	uint32_t lo = c.bucket_off[bigram];
+	const uint32_t end = c.bucket_off[bigram + 1];
+	const uint32_t hi = bucket_lower_bound(c.bucket_pos, lo, end, pos, lane); /* hits are < pos */
 	if (pos > c.dict_limit) lo = bucket_lower_bound(c.bucket_pos, lo, hi, pos - c.dict_limit, lane);
 	if (c.max_scan && hi - lo > c.max_scan) lo = hi - c.max_scan;
+	const uint32_t nhits = hi - lo;
+	if (c.diag_stop == 33) { t.count += nhits & 1u; return; }
+	if (nhits == 0) return;
+	const uint32_t wpos = c.bucket_pos[lo]; /* the scan window: hits at positions [wpos, pos) */
 	const uint32_t maxlen = (c.n - pos) < MGL_MAX_MATCH ? (c.n - pos) : MGL_MAX_MATCH;
 	const uint32_t inc_type = mgl_pk_type(incumbent), inc_len = mgl_pk_len(incumbent), inc_dist = mgl_pk_dist(incumbent);
-	if (c.diag_stop == 33) { t.count += (hi - lo) & 1u; return; }
 
-	/* the two bytes that follow the target's bigram; the index keeps the same two bytes of every
-	 * hit next to its position (bucket_nx), so a hit that matches fewer than four bytes -- most of
-	 * them -- is sized without touching the input at all */
-	const uint32_t x2 = (uint32_t)c.data[pos + 2] | ((uint32_t)c.data[pos + 3] << 8);
-	/* nearest hits first: they are the cheapest to code and win ties (later in the reference's
-	 * enumeration order), so the K-th best is close to final after the first batch and almost
-	 * every farther hit is turned away by the lower-bound test alone */
-	const uint32_t nhits = hi - lo;
-	/* Two sources feed the pricing code, nearest entries first in both.
-	 *   long:  the run of the four-byte order (quad_pos) whose entries share the target's next two
-	 *          bytes as well -- exactly the hits that match >= 4 bytes, positions ascending, cut to the
-	 *          same window; their first eight further input bytes are gathered one batch ahead.
-	 *   short: the bucket itself (bucket_pos), entries of that run skipped: hits of length 2 or 3,
-	 *          sized from bucket_nx alone.  Their price grows with the distance slot, so the scan stops
-	 *          at the first batch whose nearest entry cannot reach the K-th best any more even with the
-	 *          cheapest length and the cheapest slot from there on (sufmin). */
-	uint64_t x4;
-	__builtin_memcpy(&x4, c.data + pos + 4, 8);
-	const uint32_t x2be = ((uint32_t)c.data[pos + 2] << 8) | (uint32_t)c.data[pos + 3];
-	uint32_t qlo, qhi;
-	{
-		const uint32_t b_lo = c.bucket_off[bigram];
-		const uint32_t qa = nx_lower_bound(c.quad_nx, b_lo, end, x2be, lane);
-		const uint32_t qb = x2be == 0xFFFFu ? end : nx_lower_bound(c.quad_nx, qa, end, x2be + 1u, lane);
-		qhi = bucket_lower_bound(c.quad_pos, qa, qb, pos, lane);
-		qlo = qhi;
-		if (nhits != 0) qlo = bucket_lower_bound(c.quad_pos, qa, qhi, c.bucket_pos[lo], lane); /* the bucket scan's window */
-	}
-	const uint32_t minlen_short = lencost[0] < lencost[1] ? lencost[0] : lencost[1];
-	/* a hit can only be a LONG_REP candidate if one of the four rep distances points at a position
-	 * of this bucket: decided once per query (four scalar byte pairs), not four compares per hit */
-	bool any_rep = false;
+	auto price_high_lengths = [&]() {
+		/* lengths >= 18 (the 8-bit high tree) are priced only when a match that long shows up */
+		for (uint32_t l = 18 + lane; l <= MGL_MAX_MATCH; l += 64) {
+			lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
+			lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
+		}
+		high_ready = true;
+		wave_sync();
+		uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
+		for (uint32_t l = 16 + lane; l < 272; l += 64) { a = lencost[l] < a ? lencost[l] : a; b = lencost[272 + l] < b ? lencost[272 + l] : b; }
+		for (int o = 32; o > 0; o >>= 1) {
+			const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, 64), b2 = (uint32_t)__shfl_xor((int)b, o, 64);
+			a = a2 < a ? a2 : a; b = b2 < b ? b2 : b;
+		}
+		minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
+	};
+
+	if (c.diag_stop == 34) return;
+	/* ---- LONG_REP candidates (packet_enumerator.c:48-54: a hit whose distance is rep distance i also offers
+	 * LONG_REP i at every length).  At most four hits can: the positions the four rep distances point at, when they
+	 * carry this bigram and lie inside the scan window.  They are priced here, on their own (a LONG_REP's price does
+	 * not depend on the distance), so the distance-ordered scans below deal with MATCH candidates only and can stop
+	 * on a distance bound even when a rep distance points into the bucket. */
 	{
 		const uint32_t b0 = bigram >> 8, b1 = bigram & 0xFFu;
 #pragma unroll
 		for (uint32_t k = 0; k < 4; k++) {
 			const uint32_t dk = mgl_dist_at(&w.st, k);
-			if (dk < pos) { const uint32_t rq = pos - dk - 1u; any_rep = any_rep || (c.data[rq] == b0 && c.data[rq + 1] == b1); }
+			if (dk >= pos) continue;
+			const uint32_t q = pos - dk - 1u;
+			if (q < wpos || c.data[q] != b0 || c.data[q + 1] != b1) continue;
+			/* match length, substring_enumerator.c:99-103: 64 bytes per trip */
+			uint32_t L = maxlen;
+			for (uint32_t base = 0; base < maxlen; base += 64) {
+				const uint32_t i = base + lane;
+				const bool stop = i >= maxlen || c.data[q + i] != c.data[pos + i];
+				const unsigned long long m = __ballot(stop);
+				if (m) { const uint32_t f = base + (uint32_t)__ffsll((long long)m) - 1u; L = f < maxlen ? f : maxlen; break; }
+			}
+			if (L >= 18 && !high_ready) price_high_lengths();
+			const uint32_t hdr = k == 0 ? hdr_lr0 : k == 1 ? hdr_lr1 : k == 2 ? hdr_lr2 : hdr_lr3;
+			for (uint32_t top = L; top >= 2;) {
+				const uint64_t thr = topk_threshold(t);
+				const bool nolim = thr == MGL_INVALID_COST;
+				const uint32_t lim = nolim ? 0u : (uint32_t)(thr >> 44) + 1u;
+				if (!nolim && hdr + minlen_r >= lim * top) break; /* nothing at this or any shorter length */
+				uint64_t cand = MGL_INVALID_COST;
+				if (lane + 2u <= top) {
+					const uint32_t len = top - lane;
+					const uint32_t perp = hdr + lencost[272 + len - 2];
+					if ((nolim || perp < lim * len) && !(inc_type == MGL_LONG_REP && len == inc_len && inc_dist == k)) {
+						const uint64_t key = topk_make_key(perp / len, ((uint64_t)(q + 1) << 12) | ((uint64_t)len << 3) | (1u + k));
+						if (key < thr) cand = key;
+					}
+				}
+				topk_offer(t, cand, lane);
+				top = top > 64u + 1u ? top - 64u : 0u;
+			}
 		}
+	}
+
+	/* ---- MATCH candidates: four sources, longest matches first, nearest entries first inside each.
+	 *   16+ bytes  the run of the sixteen-byte order that holds this position: entries [run start, own rank) are the
+	 *              earlier positions sharing 16 bytes; eight more bytes sit beside each entry, the rest is compared
+	 *              in the input;
+	 *   8..15      the run of the eight-byte order, entries of the deeper run skipped (their next eight bytes equal
+	 *              ours); the length comes from those eight bytes alone;
+	 *   4..7       the same with the four-byte order and its next four bytes;
+	 *   2..3       the bigram bucket, sized from the next two bytes.
+	 * Inside a source the price only grows with the distance slot, and the lengths are capped by the next source's
+	 * prefix: a scan stops at the first batch whose nearest entry cannot reach the K-th best any more even at the
+	 * cheapest length up to that cap and the cheapest slot from there on (a true lower bound: the selection stays exact). */
+	uint64_t x8, x16, x0;
+	__builtin_memcpy(&x0, c.data + pos, 8); /* bytes 0..7: byte D is what separates source D from source D + 1 */
+	__builtin_memcpy(&x8, c.data + pos + 8, 8);
+	__builtin_memcpy(&x16, c.data + pos + 16, 8);
+	const uint32_t r8 = c.oct_rank[pos], r16 = c.hex_rank[pos];
+	const uint32_t l8 = bucket_lower_bound(c.oct_pos, c.oct_run[r8], r8, wpos, lane);
+	const uint32_t l16 = bucket_lower_bound(c.hex_pos, c.hex_run[r16], r16, wpos, lane);
+	if (c.diag_stop == 35) return; /* diagnostic stops: 34 = before the rep pass (below), 35 = after it, 36..38 = after source 0..2 */
+	/* cheapest match-length price up to the eight-byte source's cap (lengths 2..17 are priced by now) */
+	uint32_t min15;
+	{
+		uint32_t m15 = lane < 14 ? lencost[lane] : 0xFFFFFFFFu;
+		for (int o = 8; o > 0; o >>= 1) { const uint32_t d2 = (uint32_t)__shfl_xor((int)m15, o, 64); m15 = d2 < m15 ? d2 : m15; }
+		min15 = uni(m15);
 	}
 	uint32_t lim32;
 	{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
+	/* price the survivors of a batch: per lane one hit at position hq with match length hL (have = lane holds one) */
+	auto price_hits = [&](uint32_t hq, uint32_t hL, bool have) {
+		if (!high_ready && __ballot(have && hL >= 18)) price_high_lengths();
+		/* one table read decides for most hits: even the cheapest conceivable price at the longest
+		 * length this hit offers does not reach the current K-th best.  lim32 = (K-th best cost + 1),
+		 * kept across batches and refreshed after offers; costs are < 2^20 and lengths <= 273, so the
+		 * products fit 32 bits (0xFFFFFFFF = no K-th best yet) */
+		const uint32_t d = pos - hq - 1u;
+		uint32_t slot = d, lb = 0;
+		if (have) {
+			if (d >= 4) { const uint32_t nlow = mgl_msb32(d) - 2; slot = nlow * 2 + (d >> nlow); }
+			lb = hdr_match + minlen_m + lbslot[slot];
+			if (lim32 != 0xFFFFFFFFu && lb >= lim32 * hL) have = false;
+		}
+		if (!__ballot(have)) return;
+		uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, tail = 0;
+		if (have) {
+			/* distance price per length context from the tables */
+			if (d >= 4) {
+				const uint32_t nlow = mgl_msb32(d) - 2;
+				tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
+			}
+			s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
+		}
+		/* Candidates of a hit: the MATCH at every length 2..L (packet_enumerator.c:48-49).  The selection is
+		 * order-independent, so each lane walks its hit from the longest length down (the cheapest per byte
+		 * first, which tightens the threshold at once) and stops as soon as even a lower bound of the price
+		 * cannot beat the current K-th best any more.  The exact perp/len division is only done for candidates
+		 * that pass the multiply test. */
+		uint32_t len = hL;
+		while (__ballot(have)) {
+			const uint64_t thr = topk_threshold(t);
+			/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
+			const bool nolim = thr == MGL_INVALID_COST;
+			const uint32_t lim = nolim ? 0u : (uint32_t)(thr >> 44) + 1u;
+			uint64_t cand = MGL_INVALID_COST;
+			while (have) {
+				if (!nolim && lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
+				const uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
+				const uint32_t perp = hdr_match + lencost[len - 2] + sc + tail;
+				const uint32_t clen = len;
+				len--;
+				if (len < 2) have = false;
+				if (!nolim && perp >= lim * clen) continue;
+				if (inc_type == MGL_MATCH && clen == inc_len && d == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
+				const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(hq + 1) << 12) | ((uint64_t)clen << 3));
+				if (key < thr) { cand = key; break; }
+			}
+			topk_offer(t, cand, lane);
+		}
+		{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
+	};
+
+	/* ---- the two long sources: 64 entries per trip, the next trip's entries in flight */
 	for (uint32_t ph = 0; ph < 2; ph++) {
-		const bool longp = ph == 0;
-		const uint32_t* spos = longp ? c.quad_pos : c.bucket_pos;
-		const uint16_t* snx = longp ? c.quad_nx : c.bucket_nx;
-		const uint32_t top = longp ? qhi : hi, cnt = longp ? qhi - qlo : nhits;
-		uint32_t q = 0, nx = 0, q1 = 0, nx1 = 0, q2 = 0, nx2 = 0;
+		if (c.diag_stop >= 36 && c.diag_stop <= 38 && ph > c.diag_stop - 36u) break;
+		const uint32_t* spos = ph == 0 ? c.hex_pos : c.oct_pos;
+		const uint64_t* snx = ph == 0 ? c.hex_nx8 : c.oct_nx8;
+		const uint32_t top = ph == 0 ? r16 : r8;
+		const uint32_t cnt = top - (ph == 0 ? l16 : l8);
+		const uint32_t lcap = ph == 0 ? maxlen : 15u;
+		uint32_t q = 0, q1 = 0;
 		uint64_t y = 0, y1 = 0;
-		if (lane < cnt) { q = spos[top - 1u - lane]; nx = snx[top - 1u - lane]; }
-		if (64u + lane < cnt) { q1 = spos[top - 65u - lane]; nx1 = snx[top - 65u - lane]; }
-		if (longp && lane < cnt) __builtin_memcpy(&y, c.data + q + 4, 8);
+		if (lane < cnt) { q = spos[top - 1u - lane]; y = snx[top - 1u - lane]; }
 		for (uint32_t hb = 0; hb < cnt; hb += 64) {
 			bool have = hb + lane < cnt;
-			if (longp && hb + 64u + lane < cnt) __builtin_memcpy(&y1, c.data + q1 + 4, 8);
-			if (hb + 128u + lane < cnt) { q2 = spos[top - 1u - (hb + 128u + lane)]; nx2 = snx[top - 1u - (hb + 128u + lane)]; }
-			const uint32_t cq = q, cnx = nx;
+			if (hb + 64u + lane < cnt) { q1 = spos[top - 65u - hb - lane]; y1 = snx[top - 65u - hb - lane]; }
+			const uint32_t cq = q;
 			const uint64_t cy = y;
-			q = q1; nx = nx1; y = y1; q1 = q2; nx1 = nx2;
-			if (c.diag_stop == 37) { t.key ^= (uint64_t)(cq + cnx); continue; }
-			if (!longp) {
+			q = q1; y = y1;
+			{
 				/* lane 0 holds the nearest entry of this batch */
 				const uint32_t dn = pos - rdlane(cq, 0) - 1u;
 				uint32_t sn = dn;
 				if (dn >= 4) { const uint32_t nl = mgl_msb32(dn) - 2; sn = nl * 2 + (dn >> nl); }
-				if (!any_rep && lim32 != 0xFFFFFFFFu && hdr_match + minlen_short + sufmin[sn] >= lim32 * 3u && c.diag_stop != 38 && c.diag_stop != 34) break;
-				if (cnx == x2) have = false; /* a >= 4-byte match: priced from the long run */
+				const uint32_t ml = ph == 0 ? minlen_m : min15;
+				if (lim32 != 0xFFFFFFFFu && hdr_match + ml + sufmin[sn] >= lim32 * lcap) break;
 			}
-			uint32_t d = 0, L = 0, repmask = 0, slot = 0;
-			uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, tail = 0;
+			uint32_t L = 0;
 			if (have) {
-				d = pos - cq - 1;
-				/* match extension, substring_enumerator.c:99-103: bytes 2 and 3 from the index, then eight
-				 * bytes per step from the input (zero-padded past its end; global memory takes unaligned
-				 * 8-byte loads) */
-				if (longp) {
-					/* four bytes match by construction of the run; eight more arrived with the entry */
-					L = 4;
-					if (c.diag_stop != 38) {
-						const uint64_t df4 = x4 ^ cy;
-						if (df4) L += ((uint32_t)__ffsll((long long)df4) - 1u) >> 3;
-						else {
-							L = 12;
-							while (L < maxlen) {
-								uint64_t x, yy;
-								__builtin_memcpy(&x, c.data + pos + L, 8);
-								__builtin_memcpy(&yy, c.data + cq + L, 8);
-								const uint64_t df = x ^ yy;
-								if (df) { L += ((uint32_t)__ffsll((long long)df) - 1u) >> 3; break; }
-								L += 8;
-							}
+				if (ph == 0) {
+					const uint64_t df = x16 ^ cy;
+					if (df) L = 16u + (((uint32_t)__ffsll((long long)df) - 1u) >> 3);
+					else {
+						/* 24 bytes match: eight bytes per step from the input (zero padded past its end) */
+						L = 24;
+						while (L < maxlen) {
+							uint64_t x, yy;
+							__builtin_memcpy(&x, c.data + pos + L, 8);
+							__builtin_memcpy(&yy, c.data + cq + L, 8);
+							const uint64_t df2 = x ^ yy;
+							if (df2) { L += ((uint32_t)__ffsll((long long)df2) - 1u) >> 3; break; }
+							L += 8;
 						}
 					}
 				} else {
-					L = ((cnx ^ x2) & 0xFFu) ? 2u : 3u; /* the third byte differs, or only the fourth */
+					const uint64_t df = x8 ^ cy;
+					if (!df) have = false; /* 16+ bytes: priced from the deeper run */
+					else L = 8u + (((uint32_t)__ffsll((long long)df) - 1u) >> 3);
 				}
 				if (L > maxlen) L = maxlen;
-				if (any_rep)
-					repmask = (w.st.dists[0] == d ? 1u : 0u) | (w.st.dists[1] == d ? 2u : 0u) | (w.st.dists[2] == d ? 4u : 0u) |
-					          (w.st.dists[3] == d ? 8u : 0u);
-				slot = d;
-				if (d >= 4) {
-					const uint32_t nlow = mgl_msb32(d) - 2;
-					slot = nlow * 2 + (d >> nlow);
+			}
+			price_hits(cq, L, have);
+		}
+	}
+	if (c.diag_stop == 36 || c.diag_stop == 37) return;
+
+	/* ---- the exact-length sources, D = 7 down to 2: an entry of the D-byte order's run whose byte D differs from
+	 * ours matches exactly D bytes (the others belong to the next source up).  These runs hold the bulk of the
+	 * entries (10^4 .. 10^5 per query in a 4 MiB window of text) and almost all of them are turned away; with one
+	 * length per source the pruning bound is one distance threshold, recomputed only when the K-th best moves: an
+	 * entry at distance >= dthr cannot qualify at length D or shorter (hdr + cheapest length price up to D +
+	 * sufmin[slot] >= lim * D, a true lower bound), and the scan of the source ends at the first such entry.  The
+	 * scan is memory latency bound, so a lane takes four consecutive entries per trip (256 per wavefront: one
+	 * 16-byte and one 4-byte load) and filters them with a subtraction and two compares each. */
+	for (uint32_t D = 7; D >= 2; D--) {
+		if (c.diag_stop == 38 && D < 4) break;
+		const uint32_t li = D - 2u;
+		const uint32_t* spos = c.xpos[li];
+		const uint8_t* snxb = c.xnxb[li];
+		uint32_t top, low;
+		if (D == 2) { top = hi; low = lo; }
+		else {
+			top = c.xrank[li][pos];
+			low = bucket_lower_bound(spos, c.xrun[li][top], top, wpos, lane);
+		}
+		const uint32_t cnt = top - low;
+		if (cnt == 0) continue;
+		const uint32_t xb = (uint32_t)(x0 >> (8u * D)) & 0xFFu; /* our byte D (D = 7: byte 7 is the top byte of x0) */
+		const uint32_t hitlen = D < maxlen ? D : maxlen;
+		/* cheapest match-length price over lengths 2..D */
+		uint32_t minup;
+		{
+			uint32_t v = lane < D - 1u ? lencost[lane] : 0xFFFFFFFFu;
+			for (int o = 4; o > 0; o >>= 1) { const uint32_t a2 = (uint32_t)__shfl_xor((int)v, o, 64); v = a2 < v ? a2 : v; }
+			minup = uni(v);
+		}
+		uint32_t dthr = 0xFFFFFFFFu, lim_seen = 0xFFFFFFFFu;
+		auto refresh_threshold = [&]() {
+			lim_seen = lim32;
+			dthr = 0xFFFFFFFFu;
+			if (lim32 == 0xFFFFFFFFu) return;
+			const uint32_t fixed = hdr_match + minup, need = lim32 * D;
+			const unsigned long long m = __ballot(need <= fixed || sufmin[lane] >= need - fixed);
+			if (m) {
+				const uint32_t sl = (uint32_t)__ffsll((long long)m) - 1u;
+				dthr = sl < 4u ? sl : ((2u | (sl & 1u)) << ((sl >> 1) - 1u)); /* first distance of that slot */
+			}
+		};
+		/* entries hb + 4 lane + r, r = 0..3 (r = 0 nearest): array indices top - 1 - e, i.e. the four words at
+		 * top - 4 - hb - 4 lane, the nearest last */
+		auto load4 = [&](uint32_t hb, uint32_t qv[4], uint32_t& yv) {
+			const uint32_t e0 = hb + 4u * lane;
+			if (e0 + 3u < cnt) {
+				const uint32_t base = top - 4u - e0;
+				uint4 qq;
+				__builtin_memcpy(&qq, spos + base, 16);
+				qv[0] = qq.w; qv[1] = qq.z; qv[2] = qq.y; qv[3] = qq.x;
+				uint32_t yy;
+				__builtin_memcpy(&yy, snxb + base, 4);
+				yv = __builtin_bswap32(yy); /* byte r of yv = entry r */
+			} else {
+				yv = 0;
+#pragma unroll
+				for (uint32_t r = 0; r < 4; r++) {
+					const bool in = e0 + r < cnt;
+					const uint32_t idx = in ? top - 1u - (e0 + r) : top - 1u;
+					qv[r] = in ? spos[idx] : pos; /* distance "-1": never passes the filter */
+					yv |= (uint32_t)snxb[idx] << (8u * r);
 				}
 			}
-			if (!high_ready && __ballot(have && L >= 18)) {
-				for (uint32_t l = 18 + lane; l <= MGL_MAX_MATCH; l += 64) {
-					lencost[l - 2] = length_cost(probs, T, MGL_OFF_LEN, l, pos_state);
-					lencost[272 + l - 2] = length_cost(probs, T, MGL_OFF_REP_LEN, l, pos_state);
-				}
-				high_ready = true;
-				wave_sync();
-				uint32_t a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
-				for (uint32_t l = 16 + lane; l < 272; l += 64) { a = lencost[l] < a ? lencost[l] : a; b = lencost[272 + l] < b ? lencost[272 + l] : b; }
-				for (int o = 32; o > 0; o >>= 1) {
-					const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, 64), b2 = (uint32_t)__shfl_xor((int)b, o, 64);
-					a = a2 < a ? a2 : a; b = b2 < b ? b2 : b;
-				}
-				minlen_m = a < minlen_m ? uni(a) : minlen_m; minlen_r = b < minlen_r ? uni(b) : minlen_r;
+		};
+		refresh_threshold();
+		uint32_t qa[4], qb[4] = { 0, 0, 0, 0 }, ya, yb = 0;
+		load4(0, qa, ya);
+		for (uint32_t hb = 0; hb < cnt; hb += 256) {
+			if (hb + 256u < cnt) load4(hb + 256u, qb, yb); /* the next trip, in flight */
+			if (lim_seen != lim32) refresh_threshold();
+			/* lane 0's first entry is the nearest of this trip */
+			if (pos - rdlane(qa[0], 0) - 1u >= dthr) break;
+			bool pr[4];
+#pragma unroll
+			for (uint32_t r = 0; r < 4; r++) {
+				const uint32_t d = pos - qa[r] - 1u; /* out-of-range slots hold q = pos: d = 0xFFFFFFFF */
+				/* byte D equal: the match goes on: priced from the next source up */
+				pr[r] = ((ya >> (8u * r)) & 0xFFu) != xb && d < dthr && d != 0xFFFFFFFFu;
 			}
-			/* one table read decides for most hits: even the cheapest conceivable price at the longest
-			 * length this hit offers does not reach the current K-th best.  lim32 = (K-th best cost + 1),
-			 * kept across batches and refreshed after offers; costs are < 2^20 and lengths <= 273, so the
-			 * products fit 32 bits (0xFFFFFFFF = no K-th best yet) */
-			uint32_t lb = 0;
-			if (have) {
-				const uint32_t lb_m = hdr_match + minlen_m + lbslot[slot];
-				const uint32_t lb_r = hdr_lr_min + minlen_r;
-				lb = (repmask && lb_r < lb_m) ? lb_r : lb_m;
-				if (lim32 != 0xFFFFFFFFu && lb >= lim32 * L && c.diag_stop != 38 && c.diag_stop != 34) have = false;
+#pragma unroll
+			for (uint32_t r = 0; r < 4; r++) {
+				if (!__ballot(pr[r]) || c.diag_stop == 39) continue; /* 39: diagnostic, the filter alone */
+				price_hits(qa[r], hitlen, pr[r]);
 			}
-			if (!__ballot(have)) continue;
-			if (have) {
-				/* distance price per length context from the tables */
-				if (d >= 4) {
-					const uint32_t nlow = mgl_msb32(d) - 2;
-					tail = d < 128 ? disttail[d] : ((nlow - 4) << 11) + aligncost[d & 15u];
-				}
-				s0 = slotcost[slot]; s1 = slotcost[64 + slot]; s2 = slotcost[128 + slot]; s3 = slotcost[192 + slot];
-			}
-			if (c.diag_stop == 34 || c.diag_stop == 38) { t.key ^= (uint64_t)(s0 + s1 + s2 + s3 + tail + L); continue; }
-			/* Candidates of a hit: for every length 2..L the MATCH and a LONG_REP per rep slot that holds
-			 * this distance (packet_enumerator.c:48-54).  The selection is order-independent, so each lane
-			 * walks its hit from the longest length down (the cheapest per byte first, which tightens the
-			 * threshold at once) and stops as soon as even a lower bound of the price cannot beat the
-			 * current K-th best any more.  The exact perp/len division is only done for candidates that
-			 * pass the multiply test. */
-			uint32_t len = L, kind = 0; /* kind 0 = MATCH, 1+i = LONG_REP i */
-			while (__ballot(have)) {
-				const uint64_t thr = topk_threshold(t);
-				/* a candidate can only qualify if perp/len <= thr_cost, i.e. perp < (thr_cost+1)*len */
-				const bool nolim = thr == MGL_INVALID_COST;
-				const uint32_t lim = nolim ? 0u : (uint32_t)(thr >> 44) + 1u;
-				uint64_t cand = MGL_INVALID_COST;
-				while (have) {
-					if (!nolim && lb >= lim * len) { have = false; break; } /* nothing at this or any shorter length */
-					uint32_t perp, ctype, cdist;
-					if (kind == 0) {
-						const uint32_t sc = len == 2 ? s0 : len == 3 ? s1 : len == 4 ? s2 : s3;
-						perp = hdr_match + lencost[len - 2] + sc + tail;
-						ctype = MGL_MATCH; cdist = d;
-					} else {
-						const uint32_t i = kind - 1;
-						perp = (i == 0 ? hdr_lr0 : i == 1 ? hdr_lr1 : i == 2 ? hdr_lr2 : hdr_lr3) + lencost[272 + len - 2];
-						ctype = MGL_LONG_REP; cdist = i;
-					}
-					const uint32_t clen = len, ckind = kind;
-					/* next candidate of this hit */
-					uint32_t nk = kind + 1;
-					while (nk <= 4 && !((repmask >> (nk - 1)) & 1u)) nk++;
-					if (nk <= 4) kind = nk; else { kind = 0; len--; if (len < 2) have = false; }
-					if ((!nolim && perp >= lim * clen) || c.diag_stop == 36) continue;
-					if (ctype == inc_type && clen == inc_len && cdist == inc_dist) continue; /* top_k_packet_finder.c:99-101 */
-					const uint64_t key = topk_make_key(perp / clen, ((uint64_t)(cq + 1) << 12) | ((uint64_t)clen << 3) | ckind);
-					if (key < thr) { cand = key; break; }
-				}
-				if (c.diag_stop != 35) topk_offer(t, cand, lane, c.diag_stop != 80);
-			}
-			{ const uint64_t th = topk_threshold(t); lim32 = th == MGL_INVALID_COST ? 0xFFFFFFFFu : (uint32_t)(th >> 44) + 1u; }
+#pragma unroll
+			for (uint32_t r = 0; r < 4; r++) qa[r] = qb[r];
+			ya = yb;
 		}
 	}
 }
@@ -680,21 +786,10 @@ __device__ uint32_t window_end_from_journal(const DevCtx& c, const mgl_pk* slab,
 /* One wavefront = one neighbour of the base slab (packet_slab_neighbour.c:154-173). */
 /* todo != nullptr: only the neighbours listed there are evaluated (the ones the incremental
  * kernel could not fit), walking from byte 0 instead of from a prefix checkpoint. */
-__global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const Control* ctl, uint64_t seed,
-                                                    uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
-                                                    const uint32_t* todo, const uint32_t* todo_count)
+__device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Control* ctl, uint64_t seed, uint64_t step_override, uint32_t K,
+                                 const NbrOut& out, uint32_t per_wave_bytes, bool from_zero, unsigned char* smem, const uint16_t* T, uint32_t j,
+                                 uint32_t lane, uint32_t wid)
 {
-	if (todo && blockIdx.x * (blockDim.x >> 6) >= *todo_count) return; /* nothing listed for this workgroup: before any load */
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint16_t* T = (uint16_t*)smem;
-	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
-	__syncthreads();
-	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	uint32_t j = blockIdx.x * (blockDim.x >> 6) + wid;
-	if (todo) {
-		if (j >= *todo_count) return;
-		j = uni(todo[j]);
-	}
 	if (j >= K) return;
 	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
 	uint16_t* probs = (uint16_t*)mine;
@@ -735,7 +830,7 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 	/* prefix: nearest checkpoint, then the unchanged packets up to the target (:165) */
 	Walk w;
 	uint64_t base_cum = 0;
-	if (todo) {
+	if (from_zero) {
 		for (uint32_t i = lane; i < b.ckpt_elems; i += 64) probs[i] = MGL_PROB_INIT;
 		walk_reset(w);
 		wave_sync();
@@ -846,6 +941,29 @@ __global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const 
 		nd++;
 	}
 	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = wend; }
+}
+
+/* todo != nullptr: only the neighbours listed there are evaluated (the ones the incremental kernels could not
+ * fit), walking from byte 0 instead of from a prefix checkpoint; the launch is a small grid that strides over
+ * the list (the host does not know its length: empty in practice, and then a workgroup costs one load). */
+__global__ void __launch_bounds__(256) k_neighbours(DevCtx c, BaseView b, const Control* ctl, uint64_t seed,
+                                                    uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
+                                                    const uint32_t* todo, const uint32_t* todo_count)
+{
+	const uint32_t waves = blockDim.x >> 6;
+	if (todo && blockIdx.x * waves >= *todo_count) return; /* nothing listed for this workgroup: before any load */
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	if (todo) {
+		const uint32_t n = *todo_count;
+		for (uint32_t slot = blockIdx.x * waves + wid; slot < n; slot += gridDim.x * waves)
+			nbr_fullwalk_one(c, b, ctl, seed, step_override, K, out, per_wave_bytes, true, smem, T, uni(todo[slot]), lane, wid);
+	} else {
+		nbr_fullwalk_one(c, b, ctl, seed, step_override, K, out, per_wave_bytes, false, smem, T, blockIdx.x * waves + wid, lane, wid);
+	}
 }
 
 /* main.c:91 -- the new best slab (after the journal has been applied) */

@@ -218,13 +218,13 @@ __global__ void __launch_bounds__(64) k_build(DevCtx c, Base2 b, Control* ctl, i
 }
 /* the tail of an incremental step in one launch: the fallback rebuild (only when k_apply_* gave
  * up) and then the step's bookkeeping (mgl_kernels3.hip) */
-__device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int adaptive);
-__global__ void __launch_bounds__(64) k_build_end(DevCtx c, Base2 b, Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
+__device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int adaptive, int form_single);
+__global__ void __launch_bounds__(64) k_build_end(DevCtx c, Base2 b, Control* ctl, int lazy_best, uint32_t* counts, int adaptive, int form_single)
 {
 	build_body(c, b, ctl, 2);
 	__threadfence();
 	wave_sync();
-	step_end_body(ctl, lazy_best, counts, adaptive);
+	step_end_body(ctl, lazy_best, counts, adaptive, form_single);
 }
 
 /* ================================================================== change lists */
@@ -663,31 +663,20 @@ struct BigScratch {
 #define MGL_NBR_FULL 0
 #define MGL_NBR_PICK 1
 #define MGL_NBR_REST 2
+/* one neighbour, by the wavefront `wid` of its workgroup; `unit` = the neighbour's index in this launch's slice
+ * (regular launch) or its slot in the second pass's list (BIG) */
 template <bool BIG, int MODE>
-__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
-                                                     uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
-                                                     uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
-                                                     BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate)
+__device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Control* ctl, uint64_t seed,
+                                         uint64_t step_override, uint32_t K, const NbrOut& out, uint32_t per_wave_bytes,
+                                         uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
+                                         const BigScratch& big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate,
+                                         unsigned char* smem, const uint16_t* T, uint32_t unit, uint32_t lane, uint32_t wid)
 {
-	/* the step picks one of the two forms of the regular launch on the device (k_step_end): split
-	 * while repairs are rare (their second pass costs a lone wavefront's latency), one kernel
-	 * otherwise; the form not picked returns before touching anything */
-	/* decided before anything else is loaded: a launch with nothing to do (the form not chosen, a
-	 * second pass with an empty list) costs its dispatch and one load per workgroup */
-	if (BIG) {
-		if (blockIdx.x * (blockDim.x >> 6) >= *big.todo_in_count) return;
-	} else if ((MODE == MGL_NBR_FULL) != (ctl->nbr_single != 0)) return;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint16_t* T = (uint16_t*)smem;
-	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block) */
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
-	__syncthreads();
-	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	uint32_t j = j_base + blockIdx.x * (blockDim.x >> 6) + wid; /* [j_base, j_end): the slice of the step this launch covers */
+	uint32_t j = j_base + unit; /* [j_base, j_end): the slice of the step this launch covers */
 	uint32_t slot = 0;
 	const unsigned long long t_begin = prof_acc ? __builtin_readcyclecounter() : 0ull;
 	if (BIG) {
-		slot = j;
+		slot = unit;
 		const uint32_t nflag = *big.todo_in_count;
 		if (slot >= nflag) return;
 		j = uni(big.todo_in[slot]);
@@ -827,7 +816,7 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	bool first_packet = true;
 	uint32_t guard = 0;
 	/* the second pass, too, takes the mutation's pick from the first half when there was one */
-	if ((MODE == MGL_NBR_REST || (BIG && pickrec != nullptr && ctl->nbr_single == 0)) && !mutated) {
+	if ((MODE == MGL_NBR_REST || (BIG && pickrec != nullptr)) && !mutated) { /* the host passes the pick records only when the split form ran */
 		const uint4 rec = pickrec[j];
 		if (!(rec.w & 1u)) { generate_failed = true; phase = P_OUT; }
 		else {
@@ -1073,6 +1062,34 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 		                   ((unsigned long long)((ch.n_ins + ch.n_rem) & 0xFFFu) << 40) | ((unsigned long long)(walked & 0xFFFu) << 52);
 }
 
+template <bool BIG, int MODE>
+__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
+                                                     uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
+                                                     uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
+                                                     BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate)
+{
+	/* Which form of the regular launch runs (split: pick + rest + k_sim, or the one-kernel form) is the host's
+	 * choice per block of steps (mgl_sa_run reads the device's recommendation, Control::nbr_single): only the
+	 * chosen form is launched.  The second pass is launched with a small grid whatever its list holds -- the
+	 * host does not know the count -- and strides over it; with an empty list a workgroup costs one load. */
+	const uint32_t waves = blockDim.x >> 6;
+	if (BIG && blockIdx.x * waves >= *big.todo_in_count) return;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t* T = (uint16_t*)smem;
+	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block) */
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+	if (BIG) {
+		const uint32_t n = *big.todo_in_count;
+		for (uint32_t unit = blockIdx.x * waves + wid; unit < n; unit += gridDim.x * waves)
+			nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T, unit, lane, wid);
+	} else {
+		nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T,
+		                    blockIdx.x * waves + wid, lane, wid);
+	}
+}
+
 
 /* ================================================================== k_sim
  *
@@ -1087,7 +1104,6 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
                                                            uint32_t* todo, uint32_t* todo_count)
 {
-	if (ctl->nbr_single != 0) return; /* the one-kernel form ran this step: it re-simulates on its own */
 	const uint32_t j = j_base + blockIdx.x;
 	if (j >= j_end) return;
 	const uint4 hdr = big.sim_hdr[j];

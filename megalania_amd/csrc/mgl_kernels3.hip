@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 }
 
 /* decide-only variant of the step's tail: flags for k_build's conditional run are reset there */
-__device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
+__device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int adaptive, int form_single)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) {
 		if (adaptive) {
@@ -641,7 +641,7 @@ __device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int
 			 * form); the one-kernel form is used while its measured step is shorter than that. */
 			const unsigned long long now = (unsigned long long)wall_clock64();
 			const unsigned long long dt64 = now - ctl->t_last;
-			const uint32_t cur = ctl->nbr_single ? 1u : 0u;
+			const uint32_t cur = form_single ? 1u : 0u; /* the form the host launched this step */
 			const bool dirty = counts[0] != 0 || counts[3] != 0;
 			ctl->p_dirty = (uint32_t)((int32_t)ctl->p_dirty + (((dirty ? 65536 : 0) - (int32_t)ctl->p_dirty) >> 5));
 			if (ctl->t_last != 0 && ctl->mode_steps >= 1u && dt64 < 0x7FFFFFFFull) {
@@ -658,7 +658,7 @@ __device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int
 			} else if (cur == 0u && counts[0] > 128u) {
 				want = 1u; /* a burst of repairs: hundreds of neighbours would go through the second pass */
 				ctl->p_dirty = ctl->p_dirty > 49152u ? ctl->p_dirty : 49152u;
-			} else if ((cur == 0u ? ctl->ema_single == 0 : (ctl->ema_clean == 0 && ctl->ema_dirty == 0)) ? ctl->mode_steps >= 8u : ctl->mode_steps >= 512u) {
+			} else if ((cur == 0u ? ctl->ema_single == 0 : (ctl->ema_clean == 0 && ctl->ema_dirty == 0)) ? ctl->mode_steps >= 8u : ctl->mode_steps >= 2048u) { /* a trial lasts until the host's next look, a block of steps */
 				want = 1u - cur; ctl->probing = 4; /* measure the other form for a few steps */
 			} else if ((ctl->ema_clean != 0 || ctl->ema_dirty != 0) && ctl->ema_single != 0) {
 				const uint32_t clean = ctl->ema_clean ? ctl->ema_clean : ctl->ema_dirty; /* no clean split step seen yet */
@@ -668,7 +668,8 @@ __device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int
 				if (cur == 0u) want = (unsigned long long)ctl->ema_single * 100ull < exp_split * 96ull ? 1u : 0u;
 				else want = exp_split * 100ull < (unsigned long long)ctl->ema_single * 96ull ? 0u : 1u;
 			}
-			if (want != cur) { ctl->nbr_single = want; ctl->mode_steps = 0; }
+			/* a recommendation: the host adopts it at its next look at the control block (mgl_sa_run) */
+			if (want != (ctl->nbr_single ? 1u : 0u)) { ctl->nbr_single = want; ctl->mode_steps = 0; }
 		}
 		if (lazy_best) {
 			/* a new best: the base now is the best slab's; any other accepted move: they part ways
@@ -681,9 +682,9 @@ __device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int
 		for (int i = 0; i < 4; i++) { counts[4 + i] = counts[i]; counts[i] = 0; }
 	}
 }
-__global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int adaptive)
+__global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int adaptive, int form_single)
 {
-	step_end_body(ctl, lazy_best, counts, adaptive);
+	step_end_body(ctl, lazy_best, counts, adaptive, form_single);
 }
 
 /* ================================================================== base snapshots

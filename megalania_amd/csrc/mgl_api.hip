@@ -331,7 +331,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
 			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), 4096u + sa->per_wave_rest, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
-			                   sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
+			                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
 			HIPCHK(hipEventRecord(sa->ev_rest[h], st));
 			/* the second half's re-simulation, several wavefronts per neighbour; a neighbour with more touched contexts
 			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
@@ -353,7 +353,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	const uint32_t bigblocks = bigneed < 1024u ? bigneed : 1024u; /* the kernel strides over its list */
 	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   (unsigned long long*)nullptr, sa->big, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
+	                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, sa->big, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
 	/* and whatever overflowed even that: exact full walk from byte 0 (a small grid strides over the list) */
 	if (split_now) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
@@ -1301,6 +1301,18 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 19: src = sa->d_quad_nx; sz = sizeof(uint16_t) * (sa->n - 1); break;
 	case 12: src = sa->d_bucket_off; sz = sizeof(uint32_t) * 65537; break;
 	case 13: src = sa->d_bucket_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 30: case 31: case 32: case 33: case 34: case 35: src = sa->d_xpos[what - 30]; sz = sizeof(uint32_t) * (sa->n - 1); break; /* exact-length orders D = what - 28 */
+	case 40: case 41: case 42: case 43: case 44: case 45: src = sa->d_xrank[what - 40]; sz = src ? sizeof(uint32_t) * (sa->n - 1) : 0; break;
+	case 50: case 51: case 52: case 53: case 54: case 55: src = sa->d_xrun[what - 50]; sz = src ? sizeof(uint32_t) * (sa->n - 1) : 0; break;
+	case 60: case 61: case 62: case 63: case 64: case 65: src = sa->d_xnxb[what - 60]; sz = sa->n - 1; break;
+	case 70: src = sa->d_oct_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 71: src = sa->d_oct_rank; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 72: src = sa->d_oct_run; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 73: src = sa->d_oct_nx8; sz = sizeof(uint64_t) * (sa->n - 1); break;
+	case 74: src = sa->d_hex_pos; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 75: src = sa->d_hex_rank; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 76: src = sa->d_hex_run; sz = sizeof(uint32_t) * (sa->n - 1); break;
+	case 77: src = sa->d_hex_nx8; sz = sizeof(uint64_t) * (sa->n - 1); break;
 	case 21: src = sa->nbr.win; sz = sizeof(uint32_t) * 2 * sa->cfg.neighbours_per_step; break; /* windows of the last costed neighbours */
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");

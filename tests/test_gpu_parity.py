@@ -296,6 +296,67 @@ def test_pb2_elf_shaped_properties():
     sa.close()
 
 
+def test_c5_full_size_with_bucket_cap():
+    """BASELINE configs[4] at full size: 1 MiB ELF-shaped, pb = 2, bucket scan capped at the 4 096 nearest hits
+    (the reference scans every hit: > 10^6 candidates inside a zero run; the cap is the same rule in
+    the oracle, for_each_substring).  Top-K inside the longest zero run and sampled neighbours of an evolved slab
+    equal the oracle's; pb != 0 has no reference implementation (parity unpinned), the stream decodes."""
+    data, _ = corpus.config_input("c5")
+    n, K, seed, cap = len(data), 4096, 1673551, 4096
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed, pb=2, max_bucket_scan=cap, iters_per_epoch=n)
+    o = Oracle(data, pb=2, dict_limit=0x400000, max_bucket_scan=cap)
+    base = literal_slab(n)
+    z = np.frombuffer(data, dtype=np.uint8) == 0
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], z.view(np.int8), [0]])))
+    starts, ends = edges[::2], edges[1::2]
+    longest = int(np.argmax(ends - starts))
+    assert ends[longest] - starts[longest] > 2000  # the padded tables of an ELF
+    for p in (int(starts[longest]) + 1500, int((starts[longest] + ends[longest]) // 2), int(ends[longest]) - 3):
+        got_pk, got_cost = sa.top_k(P(base), p)
+        want_pk, want_cost = o.top_k(base, p, mode=1)
+        assert [int(x) for x in got_cost] == [int(x) for x in want_cost], p
+        assert as_list(got_pk) == as_list(want_pk), p
+    st = sa.run(40)  # the default accept mode: bulk steps from the start
+    assert st["bulk_steps"] > 0 and st["full_rebuilds"] == 0
+    cur, cost = sa.current()
+    slab = np.ascontiguousarray(cur).astype(base.dtype)
+    assert cost == o.cost_slab(slab)["total"]
+    costs, nd, diffs = sa.neighbours(1000)
+    for j in range(0, K, 331):
+        ok, c, od = o.neighbour(slab, seed, 1000, j, keep=False)
+        assert int(costs[j]) == (c if ok else binding.INVALID_COST), j
+    best, _ = sa.best()
+    assert lzma.decompress(binding.emit_stream(data, best, pb=2), format=lzma.FORMAT_ALONE) == data
+    sa.close()
+
+
+def test_c4_shape_100_mb():
+    """BASELINE configs[3], one GPU's share: 100 000 000 B enwik-shaped, 16 384 neighbours/step.  Size-independent
+    properties after a few steps of the default accept mode (bulk and single): device cost == an independent CPU walk
+    of the device's slab, sampled neighbours of that slab == oracle (cost and journal), no fallback to the serial
+    builder, no neighbour lost to the full-walk last resort."""
+    data, _ = corpus.config_input("c4")
+    n, K, seed = len(data), 16384, 1673551
+    sa = binding.SA(data, neighbours_per_step=K, seed=seed, iters_per_epoch=n)
+    o = Oracle(data, dict_limit=0x400000)
+    st = sa.run(6)
+    assert st["steps"] == 6 and st["full_rebuilds"] == 0 and st["fallback_neighbours"] == 0
+    sa.set_accept_mode("single")
+    st2 = sa.run(3)  # the incremental accept path at this size
+    assert st2["accepted"] == 3 and st2["full_rebuilds"] == 0 and st2["fallback_neighbours"] == 0
+    cur, cost = sa.current()
+    slab = np.ascontiguousarray(cur).astype(literal_slab(1).dtype)
+    assert cost == o.cost_slab(slab)["total"]
+    costs, nd, diffs = sa.neighbours(77)
+    for j in (5, 9000):
+        ok, c, od = o.neighbour(slab, seed, 77, j, keep=False)
+        assert int(costs[j]) == (c if ok else binding.INVALID_COST), j
+        if ok:
+            got = [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in diffs[j][: nd[j]]]
+            assert got == [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in od], j
+    sa.close()
+
+
 @pytest.mark.parametrize("cfg,size", [("c2", 100000), ("c5", 200000), ("c1", 4096), ("c2", 4097), ("c2", 2), ("c2", 3)])
 def test_match_index_built_on_device(cfg, size):
     """substring_enumerator.c:26-47: positions bucketed by leading bigram, ascending inside a
@@ -320,6 +381,28 @@ def test_match_index_built_on_device(cfg, size):
     got_qnx = sa.debug_dump(19, np.uint16)
     assert (got_quad == want_quad).all()
     assert (got_qnx == (key4[want_quad] & 0xFFFF).astype(np.uint16)).all()
+    # the deeper orders top-K scans by length (mgl_index.hip): positions by their first D bytes, then by position;
+    # rank = inverse permutation; run start = first entry with the same D bytes; the byte(s) behind the prefix
+    dp = np.concatenate([d, np.zeros(32, dtype=np.uint32)]).astype(np.uint8)
+    for D, sel in ((3, (31, 41, 51, 61)), (5, (33, 43, 53, 63)), (7, (35, 45, 55, 65)), (8, (70, 71, 72, 73)), (16, (74, 75, 76, 77))):
+        cols = np.stack([dp[idx + k] for k in range(D)])           # D x m
+        want = np.lexsort(cols[::-1]).astype(np.uint32)            # stable: ties keep position order
+        got = sa.debug_dump(sel[0], np.uint32)
+        assert (got == want).all(), D
+        rank = sa.debug_dump(sel[1], np.uint32)
+        assert (rank[want] == np.arange(m, dtype=np.uint32)).all(), D
+        keys = cols[:, want].T                                     # m x D, sorted
+        head = np.ones(m, dtype=bool)
+        head[1:] = (keys[1:] != keys[:-1]).any(axis=1)
+        want_run = np.maximum.accumulate(np.where(head, np.arange(m), 0)).astype(np.uint32)
+        assert (sa.debug_dump(sel[2], np.uint32) == want_run).all(), D
+        if D < 8:
+            assert (sa.debug_dump(sel[3], np.uint8) == dp[want + D]).all(), D
+        else:
+            nx = np.zeros(m, dtype=np.uint64)
+            for k in range(8):
+                nx |= dp[want + D + k].astype(np.uint64) << np.uint64(8 * k)
+            assert (sa.debug_dump(sel[3], np.uint64) == nx).all(), D
     sa.close()
 
 

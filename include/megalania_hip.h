@@ -216,7 +216,7 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
  * 4 on-walk bitmap, 5 special bitmap, 6 special-state records, 7 dense checkpoints, 8 chain
  * capacities, 9 phase-cycle counters (MGL_F_PROFILE), 10 per-step overflow / repair counters,
  * 11 parallel-builder totals, 12 / 13 match index (bucket offsets / positions), 14 accept-path
- * counters, 15 pick records, 16 the control block, 21 the windows (target, end) of the last costed neighbours,
+ * counters, 15 pick records, 16 the control block, 21 the windows (target, end) of the last costed neighbours, 22 their soft ends | dep << 31,
  * 30-35 / 40-45 / 50-55 / 60-65 positions / ranks / run starts / next byte of the exact-length orders D = 2..7,
  * 70-73 and 74-77 positions, ranks, run starts, next eight bytes of the 8- and 16-byte orders.
  * mgl_debug_set: key 0 = stop the neighbour kernels after a phase (tools/phase_cost.py), 50 =

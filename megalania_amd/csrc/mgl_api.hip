@@ -391,14 +391,14 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_hex_pos); dfree(sa->d_hex_rank); dfree(sa->d_hex_run); dfree(sa->d_oct_nx8); dfree(sa->d_hex_nx8);
 	free_base(sa->base); free_base(sa->scratch);
 	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
-	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.win); dfree(sa->nbr.dpos);
+	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.win); dfree(sa->nbr.win2); dfree(sa->nbr.dpos);
 	dfree(sa->bulk.ckey); dfree(sa->bulk.cwin); dfree(sa->bulk.taken); dfree(sa->bulk.hdr);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	free_b2(sa->b2, false);
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
 	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
-	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
+	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.rep_free); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
@@ -553,9 +553,11 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMalloc(&sa->nbr.walked, sizeof(uint32_t) * K));
 	HIPCHK(hipMalloc(&sa->nbr.win, sizeof(uint32_t) * 2 * K));
 	HIPCHK(hipMemset(sa->nbr.win, 0xFF, sizeof(uint32_t) * 2 * K));
+	HIPCHK(hipMalloc(&sa->nbr.win2, sizeof(uint32_t) * K));
+	HIPCHK(hipMemset(sa->nbr.win2, 0xFF, sizeof(uint32_t) * K));
 	memset(&sa->bulk, 0, sizeof sa->bulk);
 	HIPCHK(hipMalloc(&sa->bulk.ckey, sizeof(uint64_t) * K));
-	HIPCHK(hipMalloc(&sa->bulk.cwin, sizeof(uint2) * K));
+	HIPCHK(hipMalloc(&sa->bulk.cwin, sizeof(uint4) * K));
 	HIPCHK(hipMalloc(&sa->bulk.taken, sizeof(uint32_t) * K));
 	HIPCHK(hipMalloc(&sa->bulk.hdr, sizeof(unsigned long long) * 8));
 	{
@@ -617,6 +619,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&pb.st_in, sizeof(uint32_t) * 8 * (size_t)pb.nblk));
 			HIPCHK(hipMalloc(&pb.hist, sizeof(uint32_t) * (size_t)pb.nblk * ckpt_elems));
 			HIPCHK(hipMalloc(&pb.acc, sizeof(unsigned long long) * 8));
+			HIPCHK(hipMalloc(&pb.rep_free, sizeof(uint32_t)));
+			HIPCHK(hipMemset(pb.rep_free, 0, sizeof(uint32_t)));
 			pb.seg_cap = b.pool_cap / MGL_PB_SEG + ckpt_elems + 64u;
 			HIPCHK(hipMalloc(&pb.seg_off, sizeof(uint32_t) * (ckpt_elems + 1)));
 			HIPCHK(hipMalloc(&pb.unres, pb.seg_cap));
@@ -1274,7 +1278,7 @@ extern "C" int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs,
 extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes)
 {
 	if (!sa || !out || !bytes) return fail(MGL_EINVAL, "null argument");
-	if (!sa->incremental && what != 21) return fail(MGL_EINVAL, "mgl_debug_dump: handle runs the full-walk engine");
+	if (!sa->incremental && what != 21 && what != 22) return fail(MGL_EINVAL, "mgl_debug_dump: handle runs the full-walk engine");
 	HIPCHK(hipSetDevice(sa->device));
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	const Base2& b = sa->b2;
@@ -1313,6 +1317,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 75: src = sa->d_hex_rank; sz = sizeof(uint32_t) * (sa->n - 1); break;
 	case 76: src = sa->d_hex_run; sz = sizeof(uint32_t) * (sa->n - 1); break;
 	case 77: src = sa->d_hex_nx8; sz = sizeof(uint64_t) * (sa->n - 1); break;
+	case 22: src = sa->nbr.win2; sz = sizeof(uint32_t) * sa->cfg.neighbours_per_step; break; /* soft ends | dep << 31 */
 	case 21: src = sa->nbr.win; sz = sizeof(uint32_t) * 2 * sa->cfg.neighbours_per_step; break; /* windows of the last costed neighbours */
 	case 11: src = sa->pb.acc; sz = sa->pb.acc ? sizeof(unsigned long long) * 8 : 0; break; /* parallel builder totals */
 	default: return fail(MGL_EINVAL, "mgl_debug_dump: unknown selector");

@@ -98,6 +98,7 @@ struct Control {
 	uint32_t taken;          /* neighbours the last step took */
 	uint32_t bulk_was_best;  /* bulk step: the base held the best slab's structures when the step began */
 	uint32_t bulk_need_undo; /* bulk step: the best slab has to be restored from the new one + the undo log */
+	uint32_t rep_free_from;  /* the base parse holds no SHORT_REP / LONG_REP packet at or after this position (0: none at all) */
 };
 #define MGL_ERR_REBUILD_MISMATCH 1u
 #define MGL_ERR_WALK_OVERRUN 2u
@@ -111,6 +112,8 @@ struct NbrOut {
 	uint32_t* walked;  /* K: packets costed by the neighbour (from its checkpoint on) */
 	uint32_t* win;     /* 2 K: target position; first position from which neighbour and base are coded
 	                    * identically again (n if never), or MGL_WIN_NONE / MGL_WIN_DROPPED with an invalid cost */
+	uint32_t* win2;    /* K: soft end of the window (first meeting point inside the base's rep-free tail, else the end)
+	                    * | bit 31: a rep packet inside the window reads a rep distance from before it */
 	uint32_t* dpos;    /* K x MGL_MAX_DIFFS */
 	mgl_pk* dold;
 	mgl_pk* dnew;

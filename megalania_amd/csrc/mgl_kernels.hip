@@ -646,7 +646,8 @@ __global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* c
 	uint64_t bits = 0;
 	if (w.st.pos & 63u) bits = b.onwalk[word] & ((1ull << (w.st.pos & 63u)) - 1ull);
 
-	uint32_t guard = 0;
+	uint32_t guard = 0, rep_from = ci == 0 ? 0u : uni(ctl->rep_free_from); /* a restart keeps what lies before it */
+	if (ci != 0 && rep_from > w.st.pos) rep_from = 0xFFFFFFFFu; /* unknown once the tail is rewalked: re-derived below */
 	while (w.st.pos < c.n) {
 		const uint32_t pos = w.st.pos;
 		if (++guard > c.n) { if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); break; }
@@ -670,6 +671,7 @@ __global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* c
 			type = MGL_LITERAL; len = 1; dist = 0;
 			if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
 		}
+		if (type == MGL_SHORT_REP || type == MGL_LONG_REP) rep_from = pos + 1u;
 		walk_packet<true>(w, c, probs, T, type, dist, len, lane);
 		if (cum_out) {
 			uint64_t cum = base_cum + wave_sum64(w.acc);
@@ -686,6 +688,8 @@ __global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* c
 	if (final_probs) for (uint32_t i = lane; i < c.L.total; i += 64) final_probs[i] = probs[i];
 	if (lane == 0) {
 		ctl->packets = w.packets;
+		/* a partial rewalk that met no rep packet cannot tell where the rep-free tail starts: 0 only when it is known */
+		ctl->rep_free_from = rep_from == 0xFFFFFFFFu ? c.n : rep_from;
 		ctl->rebuild_cost = total;
 		ctl->final_ctx_state = w.st.ctx_state;
 		ctl->final_dists[0] = w.st.dists[0]; ctl->final_dists[1] = w.st.dists[1];
@@ -762,25 +766,39 @@ __device__ __forceinline__ mgl_pk journal_or_base(const Journal& jn, const mgl_p
  * mutated one (the incremental kernel stops its two-pointer walk there).  The
  * full-walk engine has walked to the end of the file, so it finds the point afterwards from the
  * journal.  `st` = walk state at the target (uniform). */
-__device__ uint32_t window_end_from_journal(const DevCtx& c, const mgl_pk* slab, const Journal& jn, mgl_wstate st, uint32_t lane)
+struct WinInfo { uint32_t end, soft; };
+__device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, const Journal& jn, mgl_wstate st, uint32_t rep_free, uint32_t lane)
 {
 	mgl_wstate nb = st, bs = st;
-	uint32_t count = 0;
+	uint32_t count = 0, wsoft = 0xFFFFFFFFu, taint = 0xFu, dep = 0u, wend;
 	bool first = true;
 	for (;;) {
-		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state && nb.dists[0] == bs.dists[0] &&
-		    nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] && nb.dists[3] == bs.dists[3]) return nb.pos;
-		if (nb.pos >= c.n && bs.pos >= c.n) return c.n;
+		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state) {
+			if (wsoft == 0xFFFFFFFFu && nb.pos >= rep_free) wsoft = nb.pos;
+			if (nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] && nb.dists[3] == bs.dists[3]) { wend = nb.pos; break; }
+		}
+		if (nb.pos >= c.n && bs.pos >= c.n) { wend = c.n; break; }
 		if (nb.pos <= bs.pos && nb.pos < c.n) {
 			if (!first && count < 8) count++;
 			first = false;
 			const mgl_pk pk = uni64(journal_or_base(jn, slab, nb.pos, lane));
-			mgl_advance(&nb, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk));
+			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk);
+			if (wsoft == 0xFFFFFFFFu) {
+				if (ntype == MGL_SHORT_REP) dep |= taint & 1u;
+				else if (ntype == MGL_LONG_REP) dep |= (taint >> ndist) & 1u;
+			}
+			if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;
+			else if (ntype == MGL_LONG_REP) taint = (taint & ~((2u << ndist) - 1u)) | ((taint & ((1u << ndist) - 1u)) << 1) | ((taint >> ndist) & 1u);
+			mgl_advance(&nb, ntype, ndist, mgl_pk_len(pk));
 		} else {
 			const mgl_pk pk = uni64(slab[bs.pos]);
 			mgl_advance(&bs, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk));
 		}
 	}
+	WinInfo wi;
+	wi.end = wend;
+	wi.soft = (wsoft < wend ? wsoft : wend) | (dep << 31);
+	return wi;
 }
 
 /* One wavefront = one neighbour of the base slab (packet_slab_neighbour.c:154-173). */
@@ -928,7 +946,8 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
 		return;
 	}
-	const uint32_t wend = window_end_from_journal(c, b.slab, jn, st_target, lane);
+	const WinInfo wi = window_end_from_journal(c, b.slab, jn, st_target, ctl->rep_free_from, lane);
+	const uint32_t wend = wi.end;
 	/* journal out: entries whose final value equals the base value are dropped */
 	uint32_t nd = 0;
 	for (uint32_t i = 0; i < jn.count; i++) {
@@ -940,7 +959,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 		}
 		nd++;
 	}
-	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = wend; }
+	if (lane == 0) { out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = wend; out.win2[j] = wi.soft; }
 }
 
 /* todo != nullptr: only the neighbours listed there are evaluated (the ones the incremental kernels could not

@@ -52,7 +52,7 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 	Walk w;
 	walk_reset(w);
 	BitAcc on = { 0, 0 }, sp = { 0, 0 };
-	uint32_t guard = 0;
+	uint32_t guard = 0, rep_from = 0;
 	while (w.st.pos < c.n) {
 		const uint32_t pos = w.st.pos;
 		if (++guard > c.n) { if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); break; }
@@ -66,6 +66,7 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 			type = MGL_LITERAL; len = 1; dist = 0;
 			if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
 		}
+		if (type == MGL_SHORT_REP || type == MGL_LONG_REP) rep_from = pos + 1u;
 		if (type != MGL_LITERAL) {
 			sp.bits |= 1ull << (pos & 63u);
 			if (lane < 8) {
@@ -200,6 +201,7 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 	const uint64_t cost = wave_sum64(w.acc);
 	if (lane == 0) {
 		ctl->packets = npackets;
+		ctl->rep_free_from = rep_from;
 		ctl->rebuild_cost = cost;
 		ctl->final_ctx_state = w.st.ctx_state;
 		ctl->final_dists[0] = w.st.dists[0]; ctl->final_dists[1] = w.st.dists[1];
@@ -813,6 +815,10 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
 	uint32_t wend = 0; /* where the two walks meet again: the end of this neighbour's window */
+	/* for the bulk step's selection: the first meeting point -- same byte, same ctx_state --
+	 * inside the base's rep-free tail, and whether a rep packet of the neighbour reads a distance from before the window */
+	uint32_t wsoft = 0xFFFFFFFFu, taint = 0xFu, dep = 0u;
+	const uint32_t rep_free = ctl->rep_free_from;
 	bool first_packet = true;
 	uint32_t guard = 0;
 	/* the second pass, too, takes the mutation's pick from the first half when there was one */
@@ -911,6 +917,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					const bool same_ctx = nb.ctx_state == bs.ctx_state;
 					const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
 					                    nb.dists[3] == bs.dists[3];
+					if (same_ctx && wsoft == 0xFFFFFFFFu && nb.pos >= rep_free) wsoft = nb.pos;
 					if (same_ctx && same_d) break; /* the rest of the file is coded identically */
 					if (same_ctx && nb.ctx_state < 7) {
 						/* plain literals up to the next special packet code identically: skip them */
@@ -977,6 +984,13 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					first_packet = false;
 					walked++;
 					const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
+					/* which rep distances this packet reads / pushes: bit k of taint = distance k comes from before the window */
+					if (wsoft == 0xFFFFFFFFu) {
+						if (ntype == MGL_SHORT_REP) dep |= taint & 1u;
+						else if (ntype == MGL_LONG_REP) dep |= (taint >> ndist) & 1u;
+					}
+					if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;
+					else if (ntype == MGL_LONG_REP) taint = (taint & ~((2u << ndist) - 1u)) | ((taint & ((1u << ndist) - 1u)) << 1) | ((taint >> ndist) & 1u);
 					/* the base packet at the same position: identical coding cancels.  Which events a
 					 * packet produces depends on the packet, ctx_state, the position and -- for a literal
 					 * after a match -- the byte at rep distance 0; decided before anything is planned */
@@ -1056,7 +1070,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		}
 		nd++;
 	}
-	if (lane == 0) { if (!sim_deferred) out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; out.win[2u * j] = pos; out.win[2u * j + 1u] = wend; }
+	if (lane == 0) { if (!sim_deferred) out.cost[j] = total; out.ndiffs[j] = nd; out.walked[j] = walked; out.win[2u * j] = pos; out.win[2u * j + 1u] = wend; out.win2[j] = (wsoft < wend ? wsoft : wend) | (dep << 31); }
 	if (prof_acc && lane == 0) /* diagnostic: wave lifetime (40 bits) | change events (12 bits) | packets walked (12 bits) */
 		prof_acc[32 + j] = ((__builtin_readcyclecounter() - t_begin) & 0xFFFFFFFFFFull) |
 		                   ((unsigned long long)((ch.n_ins + ch.n_rem) & 0xFFFu) << 40) | ((unsigned long long)(walked & 0xFFFu) << 52);

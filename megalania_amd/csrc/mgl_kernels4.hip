@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* 
 /* ================================================================== bulk mode */
 struct BulkBuf {
 	uint64_t* ckey;     /* K: keys of the acceptable neighbours (compacted, any order) */
-	uint2* cwin;        /* K: their windows */
+	uint4* cwin;        /* K: their windows: target, end, soft end, dep */
 	uint32_t* taken;    /* K: neighbour indices taken this step */
 	unsigned long long* hdr; /* [0] acceptable [1] taken [2] valid [3] walked [4] improving [5] dropped [6] smallest taken key */
 };
@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(256) k_bulk_prep(DevCtx c, Control* ctl, NbrOu
 		if (acc) {
 			const uint32_t at = (uint32_t)base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 			bb.ckey[at] = v.key;
-			bb.cwin[at] = make_uint2(out.win[2u * j], out.win[2u * j + 1u]);
+			const uint32_t w2 = out.win2[j];
+			bb.cwin[at] = make_uint4(out.win[2u * j], out.win[2u * j + 1u], w2 & 0x7FFFFFFFu, w2 >> 31);
 		}
 	}
 	__syncthreads();
@@ -174,18 +175,29 @@ __global__ void __launch_bounds__(256) k_bulk_prep(DevCtx c, Control* ctl, NbrOu
 	}
 }
 
-/* a candidate is taken iff no candidate of smaller key overlaps its window; the taken ones write their
+/* Two neighbours cannot both be taken -- with A the one that starts first -- unless B starts at or after A's soft
+ * end (from there on A's walk is the base's, packet for packet, and nothing reads the rep distances that may still
+ * differ) and either B is self-contained (no rep packet of B reads a distance from before its window) or B starts
+ * at or after A's end (where the rep distances agree again).  windows = (target, end, soft end, dep). */
+__device__ __forceinline__ bool windows_conflict(const uint4& x, const uint4& y)
+{
+	const bool xf = x.x <= y.x;
+	const uint4 a = xf ? x : y, b = xf ? y : x;
+	if (a.x == b.x) return true;
+	return !(a.z <= b.x && (b.w == 0u || a.y <= b.x));
+}
+/* a candidate is taken iff no candidate of smaller key conflicts with it; the taken ones write their
  * journals into the slab (their windows are pairwise disjoint, so no two of them touch one entry) */
 __global__ void __launch_bounds__(256) k_bulk_select(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab)
 {
 	__shared__ uint64_t s_key[256];
-	__shared__ uint2 s_win[256];
+	__shared__ uint4 s_win[256];
 	const uint32_t n = (uint32_t)bb.hdr[0];
 	if (blockIdx.x * blockDim.x >= n) return;
 	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool mine = a < n;
 	const uint64_t key = mine ? bb.ckey[a] : 0ull;
-	const uint2 w = mine ? bb.cwin[a] : make_uint2(0u, 0u);
+	const uint4 w = mine ? bb.cwin[a] : make_uint4(0u, 0u, 0u, 0u);
 	bool lose = false;
 	for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
 		__syncthreads();
@@ -194,7 +206,7 @@ __global__ void __launch_bounds__(256) k_bulk_select(Control* ctl, NbrOut out, B
 		const uint32_t cnt = (n - t0) < 256u ? (n - t0) : 256u;
 		if (mine && !lose)
 			for (uint32_t i = 0; i < cnt; i++)
-				lose = lose || (s_key[i] < key && s_win[i].x < w.y && w.x < s_win[i].y);
+				lose = lose || (s_key[i] < key && windows_conflict(s_win[i], w));
 	}
 	if (!mine || lose) return;
 	const uint32_t j = (uint32_t)(key & 0xFFFFFu);

@@ -859,27 +859,50 @@ static orc_packet base_at(const orc_packet* slab, const journal* jn, size_t p)
  * and the base's walk stand on the same byte with the same ctx_state and rep distances, at least
  * three repair packets after the mutated one (the first three may still turn literals into short
  * reps, packet_slab_neighbour.c:90-98) -- from there on both parses are coded identically.  n when
- * they never meet again.  This is where the device's two-pointer walk stops. */
-static size_t window_end(const orc_ctx* c, const orc_packet* slab, const journal* jn, size_t target)
+ * they never meet again.  This is where the device's two-pointer walk stops.
+ *
+ * Two refinements for the bulk step's selection.  soft_end: the first such meeting
+ * point -- same byte, same ctx_state, three repair packets done -- that lies in the part of the base parse
+ * with no SHORT_REP / LONG_REP packet at or after it (positions >= rep_free_from): the rep distances may
+ * still differ there, but nothing from there on reads them, so a second neighbour may start there provided
+ * it is self-contained.  dep: the neighbour is NOT self-contained -- some SHORT_REP / LONG_REP packet of its
+ * parse inside the window reads a rep distance that was pushed before the window. */
+typedef struct { size_t end, soft_end; int dep; } window_info;
+static window_info window_end(const orc_ctx* c, const orc_packet* slab, const journal* jn, size_t target, size_t rep_free_from)
 {
+	window_info wi = { c->n, (size_t)-1, 0 };
 	wstate bs = { 0, 0, { 0, 0, 0, 0 } };
 	while (bs.pos < target) wstate_advance(&bs, base_at(slab, jn, bs.pos));
 	wstate nb = bs;
-	unsigned count = 0;
+	unsigned count = 0, taint = 0xF; /* bit k: rep distance k was pushed before the window */
 	int first = 1;
 	for (;;) {
-		if (!first && nb.pos == bs.pos && count >= 3 && wstate_same(&nb, &bs)) return nb.pos;
-		if (nb.pos >= c->n && bs.pos >= c->n) return c->n;
+		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state) {
+			if (wi.soft_end == (size_t)-1 && nb.pos >= rep_free_from) wi.soft_end = nb.pos;
+			if (wstate_same(&nb, &bs)) { wi.end = nb.pos; break; }
+		}
+		if (nb.pos >= c->n && bs.pos >= c->n) { wi.end = c->n; break; }
 		if (nb.pos <= bs.pos && nb.pos < c->n) {
 			if (!first && count < 8) count++;
 			first = 0;
-			wstate_advance(&nb, slab[nb.pos]);
+			const orc_packet pk = slab[nb.pos];
+			if (wi.soft_end == (size_t)-1) { /* inside the (soft) window: what the packet reads */
+				if (pk.type == ORC_SHORT_REP) wi.dep |= taint & 1u;
+				else if (pk.type == ORC_LONG_REP) wi.dep |= (taint >> pk.dist) & 1u;
+			}
+			if (pk.type == ORC_MATCH) taint = (taint << 1) & 0xFu;
+			else if (pk.type == ORC_LONG_REP) {
+				const unsigned k = pk.dist, bit = (taint >> k) & 1u;
+				taint = (taint & ~((2u << k) - 1u)) | ((taint & ((1u << k) - 1u)) << 1) | bit;
+			}
+			wstate_advance(&nb, pk);
 		} else {
 			wstate_advance(&bs, base_at(slab, jn, bs.pos));
 		}
 	}
+	if (wi.soft_end == (size_t)-1 || wi.soft_end > wi.end) wi.soft_end = wi.end;
+	return wi;
 }
-
 /* status: 1 = ok, 0 = no candidate at the target (main.c:81-84 retries those), -1 = dropped because
  * its journal needs more than ORC_MAX_JOURNAL distinct positions (the device's journal capacity) */
 int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
@@ -921,7 +944,18 @@ int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step,
 	if (cost) *cost = ok == 1 ? total : ~0ull;
 	if (window) {
 		window[0] = (uint32_t)target;
-		window[1] = ok == 1 ? (uint32_t)window_end(c, slab, &jn, target) : 0xFFFFFFFFu;
+		window[1] = window[2] = 0xFFFFFFFFu; window[3] = 0;
+		if (ok == 1) {
+			/* the base's rep-free tail: the journal's old values give the base back */
+			size_t from = 0;
+			for (size_t p = 0; p < c->n;) {
+				const orc_packet bp = base_at(slab, &jn, p);
+				if (bp.type == ORC_SHORT_REP || bp.type == ORC_LONG_REP) from = p + 1;
+				p += bp.len;
+			}
+			const window_info wi = window_end(c, slab, &jn, target, from);
+			window[1] = (uint32_t)wi.end; window[2] = (uint32_t)wi.soft_end; window[3] = (uint32_t)wi.dep;
+		}
 	}
 	/* compact the journal: first old value per position + final value, drop no-ops */
 	size_t nd = 0;
@@ -963,6 +997,16 @@ static uint64_t ceil_sqrt_u64(uint64_t x)
 	return r * r == x ? r : r + 1;
 }
 
+/* Two neighbours (window = target, end, soft_end, dep) cannot both be taken: with A the one that starts first,
+ * unless B starts at or after A's soft end, and either B is self-contained or B starts at or after A's end. */
+static int windows_conflict(const uint32_t* x, const uint32_t* y)
+{
+	const uint32_t* a = x[0] <= y[0] ? x : y;
+	const uint32_t* b = x[0] <= y[0] ? y : x;
+	if (a[0] == b[0]) return 1;
+	return !(a[2] <= b[0] && (b[3] == 0 || a[1] <= b[0]));
+}
+
 /* one step = K neighbours of the same base slab, then one decision.
  *
  * Every evaluation keeps the reference's own rule (main.c:86-87): neighbour j of a step is the
@@ -989,7 +1033,7 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 	uint64_t cur = *cur_io, best_cost = *best_cost_io, valid = 0, dropped = 0;
 	uint64_t* costs = (uint64_t*)malloc(sizeof(uint64_t) * K);
 	uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * K);
-	uint32_t* win = (uint32_t*)malloc(sizeof(uint32_t) * 2 * K);
+	uint32_t* win = (uint32_t*)malloc(sizeof(uint32_t) * 4 * K);
 	orc_diff* diffs = (orc_diff*)malloc(sizeof(orc_diff) * ORC_MAX_JOURNAL * (size_t)K);
 	size_t* nd = (size_t*)malloc(sizeof(size_t) * K);
 	uint8_t* take = (uint8_t*)malloc(K);
@@ -1002,7 +1046,7 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 		size_t nacceptable = 0;
 		for (uint32_t j = 0; j < K; j++) {
 			const int st = orc_neighbour_ex(c, slab, seed, s, j, 0, &costs[j], diffs + (size_t)j * ORC_MAX_JOURNAL, &nd[j],
-			                                ORC_MAX_JOURNAL, win + 2 * (size_t)j);
+			                                ORC_MAX_JOURNAL, win + 4 * (size_t)j);
 			keys[j] = ~0ull;
 			if (st == -1) dropped++;
 			if (st != 1) continue;
@@ -1036,7 +1080,7 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 				if (keys[j] == ~0ull) continue;
 				int lose = 0;
 				for (uint32_t i = 0; i < K && !lose; i++)
-					lose = keys[i] < keys[j] && win[2 * i] < win[2 * j + 1] && win[2 * j] < win[2 * i + 1];
+					lose = keys[i] < keys[j] && windows_conflict(win + 4 * (size_t)i, win + 4 * (size_t)j);
 				if (!lose) { take[j] = 1; ntaken++; }
 			}
 		}

@@ -82,8 +82,10 @@ uint32_t orc_draw(uint64_t seed, uint64_t step, uint32_t j, uint32_t n);
 int orc_neighbour(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
                   int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap);
 /* the same with the neighbour's status (1 ok, 0 no candidate, -1 dropped by the 64-entry journal
- * capacity of the device) and its window: window[0] = target position, window[1] = first position
- * from which neighbour and base are coded identically again (n if never; ~0 when not ok) */
+ * capacity of the device) and its window, 4 words: [0] target position, [1] first position from which
+ * neighbour and base are coded identically again (n if never; ~0 when not ok), [2] the soft end (the first
+ * meeting point in the rep-free tail of the base parse, else = [1]), [3] 1 when a rep packet of the neighbour
+ * inside the window reads a rep distance from before the window */
 int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step, uint32_t j,
                      int keep, uint64_t* cost, orc_diff* diffs, size_t* ndiffs, size_t cap, uint32_t* window);
 /* Run batched steps [step_begin, step_end) of K neighbours; mirrors mgl_sa_run.  iter0 = evaluations

@@ -196,14 +196,14 @@ class Oracle:
         return bool(ok), cost.value, diffs[: nd.value].copy()
 
     def neighbour_ex(self, slab, seed, step, j, keep=False, cap=4096):
-        """status (1 ok / 0 no candidate / -1 dropped by the journal capacity), cost, diffs, (target, window end)"""
+        """status (1 ok / 0 no candidate / -1 dropped by the journal capacity), cost, diffs, (target, end, soft end, dep)"""
         cost = C.c_uint64(0)
         nd = C.c_size_t(0)
         diffs = np.zeros(cap, dtype=DIFF)
-        win = np.zeros(2, dtype=np.uint32)
+        win = np.zeros(4, dtype=np.uint32)
         st = self.L.orc_neighbour_ex(self.h, ptr(slab), seed, step, j, int(keep), C.addressof(cost), ptr(diffs),
                                      C.addressof(nd), cap, ptr(win))
-        return st, cost.value, diffs[: min(nd.value, cap)].copy(), (int(win[0]), int(win[1]))
+        return st, cost.value, diffs[: min(nd.value, cap)].copy(), tuple(int(x) for x in win)
 
     def set_temperature(self, temperature: int):
         self.L.orc_set_temperature(self.h, temperature)

@@ -191,6 +191,36 @@ def test_sa_run_trajectory_vs_oracle(fullwalk, accept):
     sa.close()
 
 
+@pytest.mark.parametrize("name,K,steps", [("enwik30k", 2048, 120), ("lorem4k", 512, 200), ("reps", 256, 200), ("zeros600", 64, 100), ("elf64k", 2048, 120)])
+def test_bulk_steps_keep_the_parse_valid(name, K, steps):
+    """Hundreds of neighbours taken at once, step after step: every few steps the slab must still be a parse of the
+    input whose every packet reproduces it (k_validate through mgl_sa_set_slab on a second handle), cost what an
+    independent CPU walk says, and decode.  (Soft window ends let a neighbour start inside another one's tail: this
+    is where an invalid combination would show.)"""
+    data = {"enwik30k": lambda: corpus.enwik_like(30000, 0x81), "lorem4k": lambda: corpus.lorem(4096),
+            "reps": lambda: (b"abcabcabd" * 300 + corpus.lorem(700)) * 2, "zeros600": lambda: b"\0" * 600 + corpus.lorem(200) + b"\0" * 300,
+            "elf64k": lambda: corpus.config_input("c5", 65536)[0]}[name]()
+    n = len(data)
+    sa = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=77, iters_per_epoch=n)
+    chk = binding.SA(data, accept="single", neighbours_per_step=8)
+    o = Oracle(data, dict_limit=0x400000)
+    taken = 0
+    for s in range(0, steps, 20):
+        st = sa.run(20)
+        taken += st["accepted"]
+        cur, cost = sa.current()
+        slab = np.ascontiguousarray(cur).astype(literal_slab(1).dtype)
+        assert cost == o.cost_slab(slab)["total"], (name, s)
+        chk.set_slab(cur)  # raises unless every packet on the walk reproduces the input
+        assert chk.current()[1] == cost
+        assert lzma.decompress(binding.emit_stream(data, cur), format=lzma.FORMAT_ALONE) == data
+    assert taken > steps or name == "zeros600"  # several moves per step on average
+    bst, bcost = sa.best()
+    assert bcost <= cost and lzma.decompress(binding.emit_stream(data, bst), format=lzma.FORMAT_ALONE) == data
+    sa.close()
+    chk.close()
+
+
 def test_windows_and_drop_counter_vs_oracle():
     """Every neighbour's window [target, end) -- what a bulk step's selection works on -- equals the
     oracle's, on both engines, on a repetitive input whose repairs run long; and the count of
@@ -206,13 +236,14 @@ def test_windows_and_drop_counter_vs_oracle():
         sa.set_slab(P(slab))
         costs, nd, _ = sa.neighbours(777)
         win = sa.debug_dump(21, np.uint32).reshape(-1, 2)
+        win2 = sa.debug_dump(22, np.uint32)
         ndrop = 0
         for j in range(K):
             st, cost, diffs, w = o.neighbour_ex(slab, seed, 777, j)
             ndrop += st == -1
             assert (int(costs[j]) == cost) and (st == 1) == (int(costs[j]) != binding.INVALID_COST), j
             if st == 1:
-                assert (int(win[j, 0]), int(win[j, 1])) == w, (j, win[j], w)
+                assert (int(win[j, 0]), int(win[j, 1]), int(win2[j]) & 0x7FFFFFFF, int(win2[j]) >> 31) == w, (j, win[j], win2[j], w)
         sa.close()
     # the drop counter through mgl_sa_run (one single step from the same slab, both engines agree with the oracle)
     sa = binding.SA(data, accept="single", neighbours_per_step=K, seed=seed, iters_per_epoch=n)

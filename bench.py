@@ -10,13 +10,17 @@ decision, the base structures brought up to date.
 Workload.  N = 1: BASELINE configs[2], the largest single-GPU configuration -- dickens-shaped 10 192 446 B
 (synthetic, seeded: no corpora exist offline), 16 384 neighbours/step, lc=lp=pb=0, top-K 20.  N > 1:
 configs[3], one independent chain per GPU on an enwik8-shaped 100 000 000 B input, 16 384 neighbours/step
-(weak scaling), with the per-epoch best-slab exchange (one 8-byte RCCL all-reduce + one broadcast of the
-packed slab, from the C library) done once inside the timed region.  `--config` selects another one.
+(weak scaling, no data-path collective).  The per-epoch best-slab exchange (one 8-byte RCCL all-reduce + one
+broadcast of the packed slab, from the C library: configs[3] runs it every 10 000 steps) is run once, right after
+the timed steps, and timed on its own ("exchange"): it is not a step.  `--config` selects another workload.
 
 State measured.  The configs are long runs (10^5 .. 10^6 steps); what such a run does almost all of the time is
 step an *evolved* slab.  So the set-up phase first runs `--prepare-steps` search steps from the all-literal slab
 in the library's default accept mode (bulk steps while they pay, then single steps; untimed, reported under
 "prepare"), then W untimed warm-up steps, then exactly K timed steps, bracketed by barrier + device synchronise.
+At 100 MB the bulk phase of a search from the all-literal slab lasts minutes (a bulk step re-derives 28 GB of
+structures): there the set-up is the library's greedy seed (mgl_sa_seed_greedy, an evolved parse in half a second)
+and the timed steps are single-accept steps; the line says so.
 `value` = neighbour evaluations that produced a cost, summed over ranks, / max-over-ranks wall time.  The rate on
 the young slab (first steps from the all-literal slab) is reported beside it under "young_slab".
 
@@ -190,7 +194,9 @@ def main():
     ap.add_argument("--prepare-steps", type=int, default=-1,
                     help="search steps of the set-up phase (default: until the library's bulk phase is over, capped per config and at --prepare-seconds)")
     ap.add_argument("--prepare-seconds", type=float, default=90.0)
-    ap.add_argument("--accept", default="auto", choices=["auto", "single", "bulk"])
+    ap.add_argument("--accept", default=None, choices=["auto", "single", "bulk"],
+                    help="accept mode of the warm-up and timed steps (default: auto; single for inputs above 32 MB)")
+    ap.add_argument("--greedy-seed", type=int, default=-1, help="set-up from the greedy seed with this many candidates (default: 64 above 32 MB, else off)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the young-slab rate and the size gates")
@@ -232,8 +238,11 @@ def main():
     # c5 (ELF-shaped): inside long zero runs a top-K query has > 10^6 candidates in the reference; the
     # bench caps the bucket scan at the 4096 nearest hits and says so.
     props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
+    big_input = n > (32 << 20)
+    greedy = args.greedy_seed if args.greedy_seed >= 0 else (64 if big_input else 0)
+    accept = args.accept or ("single" if big_input else "auto")
     sa = binding.SA(data, neighbours_per_step=K, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=n,
-                    device=local_rank, timing=True, accept=args.accept, **props)
+                    device=local_rank, timing=True, accept="auto", **props)
     comm = None
     if dist is not None and backend == "nccl":
         comm = multi_gpu.make_comm(dist, rank, world, local_rank)  # the C library's own RCCL communicator
@@ -248,7 +257,11 @@ def main():
     # (the library's AUTO mode has left its bulk phase), every rank for itself
     t_prep = time.perf_counter()
     prep = None
-    if args.prepare_steps != 0:
+    if greedy:
+        sa.seed_greedy(greedy)
+        _, seed_cost = sa.current()
+        prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, best_cost=seed_cost, greedy_candidates=greedy)
+    elif args.prepare_steps != 0:
         prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, best_cost=0)
         cap = args.prepare_steps if args.prepare_steps > 0 else PREPARE_CAP[cfg]
         chunk = cap if args.prepare_steps > 0 else (64 if n <= (1 << 20) else 128)
@@ -261,17 +274,25 @@ def main():
                 break
     prepare = prep["steps"] if prep else 0
     t_prep = time.perf_counter() - t_prep
+    sa.set_accept_mode(accept)
     sa.run(args.warmup)
     sync()
     t0 = time.perf_counter()
     st = sa.run(args.steps)
-    if dist is not None:
-        if comm is not None:
-            multi_gpu.exchange_best_native(sa, comm)
-        else:
-            multi_gpu.exchange_best(sa, dist, device=coll_device)
     sync()
     elapsed = time.perf_counter() - t0
+    exchange = None
+    if dist is not None:
+        t1 = time.perf_counter()
+        if comm is not None:
+            winner, wcost = multi_gpu.exchange_best_native(sa, comm)
+        else:
+            winner, wcost = multi_gpu.exchange_best(sa, dist, device=coll_device)
+        sync()
+        t1 = time.perf_counter() - t1
+        exchange = {"ms": t1 * 1e3, "winner_rank": winner, "winner_est_bytes": 18 + wcost / 16384, "slab_bytes_broadcast": 8 * n,
+                    "transport": "RCCL from the C library (mgl_sa_exchange_best)" if comm is not None else f"torch.distributed/{backend} through host memory",
+                    "amortised_ms_per_step_at_10000_steps_per_exchange": t1 * 1e3 / 10000}
 
     evals, walked = st["evaluations"], st["packets_evaluated"]
     if dist is not None:
@@ -333,9 +354,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cfg}: {desc}, {n} B, {K} neighbours/step, top-K 20, lc/lp/pb={lcpb}"
                                    + (f", bucket scan capped at {props['max_bucket_scan']}" if props.get("max_bucket_scan") else "")
-                                   + f"; slab state: after {prepare} search steps from the all-literal slab (accept mode {args.accept})",
+                                   + (f"; slab state: greedy seed ({greedy} candidates); timed steps in accept mode {accept}" if greedy else
+                                      f"; slab state: after {prepare} search steps from the all-literal slab (accept mode auto); timed steps in accept mode {accept}"),
                        "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"
-                                   + (", best-slab exchange inside the timed region" if n_gpus > 1 else "")},
+                                   + (", best-slab exchange timed separately" if n_gpus > 1 else "")},
             "roofline": roof,
             "final": {"current_cost": st["current_cost"], "best_cost": st["best_cost"],
                       "est_bytes_best": 18 + st["best_cost"] / 16384, "accepted": st["accepted"],
@@ -346,8 +368,10 @@ def main():
                       "fallback_neighbours": st["fallback_neighbours"],
                       "second_pass_neighbours": st["second_pass_neighbours"]},
         }
+        if exchange:
+            out["exchange"] = exchange
         if prep:
-            out["prepare"] = {"steps": prep["steps"], "seconds": t_prep, "evaluations": prep["evaluations"], "bulk_steps": prep["bulk_steps"],
+            out["prepare"] = {"greedy_candidates": prep.get("greedy_candidates"), "steps": prep["steps"], "seconds": t_prep, "evaluations": prep["evaluations"], "bulk_steps": prep["bulk_steps"],
                               "moves_accepted": prep["accepted"], "est_bytes_best": 18 + prep["best_cost"] / 16384,
                               "evals_per_s": prep["evaluations"] / t_prep if t_prep > 0 else None}
         gates = {}

@@ -106,6 +106,7 @@ struct mgl_sa {
 	size_t b2_bytes;
 	BigScratch big;
 	uint32_t* d_todo2;
+	uint32_t* d_todo3 = nullptr; /* neighbours k_sim could not take (more touched contexts than its list holds): the late second pass */
 	uint4* d_pickstate;     /* 2 K: target, RNG position and walk state at the target (first half -> second half) */
 	uint4* d_pickrec;       /* K: picked packet, RNG position, ok flag (first half -> second half of the neighbour evaluation) */
 	bool split_nbr, adaptive; /* adaptive: the device recommends the split or the one-kernel form, the host adopts it block by block */
@@ -311,7 +312,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 		HIPCHK(hipGetLastError());
 		return MGL_OK;
 	}
-	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 4 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
+	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 8 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	const bool split_now = sa->split_nbr && !sa->form_single;
 	if (split_now) {
@@ -337,7 +338,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
 			HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
 			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
-			                   sa->nbr, sa->big, j0, j1, sa->d_todo2, sa->d_counts + 1);
+			                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 		}
 		HIPCHK(hipEventRecord(sa->ev_sim, sa->stream3));
 		for (uint32_t h = 1; h < slices; h += 2) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_rest[h], 0)); /* the walks of the other stream's slices */
@@ -351,11 +352,25 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	 * evaluation in one kernel, lists in global scratch */
 	const uint32_t bigneed = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* a slot per neighbour: none is dropped */
 	const uint32_t bigblocks = bigneed < 1024u ? bigneed : 1024u; /* the kernel strides over its list */
+	BigScratch big_now = sa->big;
+	if (!split_now || getenv("MGL_BIG_INLINE_SIM")) big_now.sim_hdr2 = nullptr; /* the one-kernel form has no k_sim launch to hand over to */
 	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, sa->big, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
+	                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
+	if (split_now) {
+		/* the second pass handed its final re-simulations to k_sim as well (headers in sim_hdr2): a small grid over its list */
+		const uint32_t sim_lds = ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + MGL_SIM2_CAP * 16u;
+		hipLaunchKernelGGL(k_sim, dim3(256), dim3(64 * MGL_SIM_WAVES), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, sa->big, 0u, K,
+		                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts);
+		/* what k_sim (either launch) could not take: a late second pass that re-simulates inline */
+		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
+		BigScratch late = sa->big;
+		late.todo_in = sa->d_todo3; late.todo_in_count = sa->d_counts + 4; late.sim_hdr2 = nullptr;
+		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 64u ? bigblocks : 64u), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
+		                   (unsigned long long*)nullptr, late, sa->d_pickrec, 0u, K, sa->d_pickstate);
+	}
 	/* and whatever overflowed even that: exact full walk from byte 0 (a small grid strides over the list) */
-	if (split_now) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks < 256u ? blocks : 256u), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
@@ -402,7 +417,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->d_todo2); dfree(sa->d_counts); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
+	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->ab.span_pos); dfree(sa->ab.span_ev); dfree(sa->ab.jobs_b); dfree(sa->ab.jobs_c);
@@ -709,8 +724,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		}
 		sa->nbr2_lds = 4096u + sa->waves_per_block2 * sa->per_wave2;
 		sa->build_lds = 4096u + ckpt_elems * 2u + ckpt_elems * 8u;
-		HIPCHK(hipMalloc(&sa->d_counts, sizeof(uint32_t) * 8)); /* [0..3] live, [4..7] the last finished step's */
-		HIPCHK(hipMemset(sa->d_counts, 0, sizeof(uint32_t) * 8));
+		HIPCHK(hipMalloc(&sa->d_counts, sizeof(uint32_t) * 16)); /* [0..7] live, [8..15] the last finished step's */
+		HIPCHK(hipMemset(sa->d_counts, 0, sizeof(uint32_t) * 16));
+		HIPCHK(hipMalloc(&sa->d_todo3, sizeof(uint32_t) * (K + 1)));
+		HIPCHK(hipMemset(sa->d_todo3, 0, sizeof(uint32_t) * (K + 1)));
 		sa->big.todo_in = sa->d_todo; sa->big.todo_in_count = sa->d_counts; sa->big.spill_ctr = sa->d_counts + 2;
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_PICK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -726,6 +743,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&g.sim_keys, sizeof(uint16_t) * 2u * sa->chg_cap * (size_t)K));
 			HIPCHK(hipMalloc(&g.sim_pos, sizeof(uint32_t) * 2u * sa->chg_cap * (size_t)K));
 			HIPCHK(hipMemset(g.sim_hdr, 0xFF, sizeof(uint4) * (size_t)K));
+			HIPCHK(hipMalloc(&g.sim_hdr2, sizeof(uint4) * (size_t)K));
+			HIPCHK(hipMemset(g.sim_hdr2, 0xFF, sizeof(uint4) * (size_t)K));
 		}
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
 		sa->form_single = !sa->split_nbr; /* one-kernel form only, or the split form until the device recommends otherwise */
@@ -748,6 +767,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			if (n > (1u << 20)) best_w = 1;
 			if (sa->pick_waves == 0 || 4096u + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = best_w;
 		}
+		HIPCHK(hipFuncSetAttribute((const void*)k_sim, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build_end, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
@@ -1246,7 +1266,7 @@ extern "C" int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs,
 	if (!sa || !costs) return fail(MGL_EINVAL, "null argument");
 	HIPCHK(hipSetDevice(sa->device));
 	int rc = launch_neighbours(sa, global_step);
-	if (rc == MGL_OK && sa->d_counts) HIPCHK(hipMemcpyAsync(sa->d_counts + 4, sa->d_counts, sizeof(uint32_t) * 4, hipMemcpyDeviceToDevice, sa->stream));
+	if (rc == MGL_OK && sa->d_counts) HIPCHK(hipMemcpyAsync(sa->d_counts + 8, sa->d_counts, sizeof(uint32_t) * 8, hipMemcpyDeviceToDevice, sa->stream));
 	if (rc) return rc;
 	const size_t K = sa->cfg.neighbours_per_step;
 	HIPCHK(hipMemcpyAsync(costs, sa->nbr.cost, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, sa->stream));
@@ -1297,7 +1317,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
-	case 10: src = sa->d_counts + 4; sz = sizeof(uint32_t) * 4; break; /* of the last finished step / mgl_neighbours call */
+	case 10: src = sa->d_counts + 8; sz = sizeof(uint32_t) * 4; break; /* of the last finished step / mgl_neighbours call */
 	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
 	case 16: src = sa->base.ctl; sz = sizeof(Control); break; /* raw control block */
 	case 15: src = sa->d_pickrec; sz = sa->d_pickrec ? sizeof(uint4) * sa->cfg.neighbours_per_step : 0; break;

@@ -650,6 +650,7 @@ struct BigScratch {
 	 * {n_ins, n_rem, direct lo, direct hi} (n_ins = ~0: nothing to do) and the two change lists */
 	uint32_t chg_cap; /* events per first-pass list (MGL_CHG_CAP, more when a step has few neighbours and LDS to spare) */
 	uint4* sim_hdr;
+	uint4* sim_hdr2; /* the same for the second pass's neighbours (k_sim's second launch); nullptr: the second pass re-simulates inline */
 	uint16_t* sim_keys; /* per neighbour: ins_key[chg_cap] | rem_key[chg_cap] */
 	uint32_t* sim_pos;  /* per neighbour: ins_pos[chg_cap] | rem_pos[chg_cap] */
 };
@@ -662,6 +663,7 @@ struct BigScratch {
  *                 chain re-simulation.  A repair that needs another top-K pick (rare) hands the
  *                 neighbour to the next pass;
  *   MGL_NBR_FULL  the whole thing in one kernel (the BIG second pass, which starts from scratch). */
+#define MGL_SIM2_CAP 2048u /* events per list k_sim's second launch takes (the second pass's neighbours) */
 #define MGL_NBR_FULL 0
 #define MGL_NBR_PICK 1
 #define MGL_NBR_REST 2
@@ -721,6 +723,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	ch.n_ins = ch.n_rem = 0; ch.direct = 0; ch.overflow = false;
 	bool too_many = false;
 	bool spilled = BIG;
+	const bool spilled_lds = false; /* BIG: the lists live in this neighbour's global scratch slot from the start */
 
 	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
 	NbrRng rng; rng.key = mgl_rng_key(seed, gstep, j); rng.n = 0;
@@ -730,6 +733,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	uint32_t target;
 	mgl_wstate nb; /* neighbour's walk state */
 	if (MODE == MGL_NBR_REST && lane == 0) big.sim_hdr[j] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+	if (BIG && big.sim_hdr2 != nullptr && lane == 0) big.sim_hdr2[j] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
 	if (MODE == MGL_NBR_REST) {
 		const uint4 s0 = pickstate[2u * j], s1 = pickstate[2u * j + 1u];
 		target = s0.x; rng.n = s0.y;
@@ -866,6 +870,15 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			if ((ch.n_ins + ch.n_rem) != 0) { sim_limit = pick_pos; sim_overlay = true; phase = P_SIM; }
 			else phase = P_TOPK;
 		}
+		if (BIG && big.sim_hdr2 != nullptr && !sim_overlay && !spilled_lds && ch.n_ins <= MGL_SIM2_CAP && ch.n_rem <= MGL_SIM2_CAP && phase == P_SIM) {
+			/* the second pass hands over its FINAL re-simulation too: k_sim's second launch reads the lists straight from this
+			 * neighbour's scratch slot into LDS and puts two wavefronts on them (here they sit in global memory in front of one
+			 * wavefront: the long-list neighbours were the slowest of the pass) */
+			if (lane == 0) big.sim_hdr2[j] = make_uint4(ch.n_ins | (slot << 12), ch.n_rem, (uint32_t)(uint64_t)ch.direct, (uint32_t)((uint64_t)ch.direct >> 32));
+			sim_deferred = true;
+			phase = P_OUT;
+			continue;
+		}
 		if (MODE == MGL_NBR_REST && phase == P_SIM) {
 			/* the second half ends here (always: it holds no re-simulation code of its own): the lists go to k_sim, which puts several wavefronts on the
 			 * contexts of one neighbour and writes the cost; journal and counters are written below */
@@ -873,6 +886,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			uint32_t* gp = big.sim_pos + (size_t)j * (2u * big.chg_cap);
 			for (uint32_t e = lane; e < ch.n_ins; e += 64) { gk[e] = ch.ins_key[e]; gp[e] = ch.ins_pos[e]; }
 			for (uint32_t e = lane; e < ch.n_rem; e += 64) { gk[big.chg_cap + e] = ch.rem_key[e]; gp[big.chg_cap + e] = ch.rem_pos[e]; }
+			/* no fence: the consumer is a later launch on a stream that waits for this one */
 			if (lane == 0) big.sim_hdr[j] = make_uint4(ch.n_ins, ch.n_rem, (uint32_t)(uint64_t)ch.direct, (uint32_t)((uint64_t)ch.direct >> 32));
 			sim_deferred = true;
 			phase = P_OUT;
@@ -1115,25 +1129,26 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 #ifndef MGL_SIM_WAVES
 #define MGL_SIM_WAVES 2u
 #endif
-__global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
-                                                           uint32_t* todo, uint32_t* todo_count)
+struct SimShared {
+	uint16_t* T;
+	uint32_t* dyn;
+	unsigned long long* sum;
+	uint32_t* nu_many; /* [0] distinct contexts, [1] too many */
+};
+template <bool FROM_BIG>
+__device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control* ctl, const NbrOut& out, const BigScratch& big, const uint4* hdrs,
+                                        uint32_t j, uint32_t* todo, uint32_t* todo_count, const SimShared& sh)
 {
-	const uint32_t j = j_base + blockIdx.x;
-	if (j >= j_end) return;
-	const uint4 hdr = big.sim_hdr[j];
-	if (hdr.x == 0xFFFFFFFFu) return; /* failed, dropped or handed to the second pass: its cost is written */
-	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
-	/* sized by the launch: one bit per context, then the two lists (positions, keys) and the context list */
-	extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-	const uint32_t cap = big.chg_cap;
-	uint32_t* s_bits = s_dyn;
-	uint32_t* s_pos = s_dyn + ((((c.L.total + 31u) >> 5) + 3u) & ~3u);
+	uint4 hdr = hdrs[j];
+	if (hdr.x == 0xFFFFFFFFu) return; /* failed, dropped or handed on: its cost is written (uniform over the workgroup) */
+	const uint32_t cap = FROM_BIG ? MGL_SIM2_CAP : big.chg_cap;
+	const uint32_t slot = FROM_BIG ? hdr.x >> 12 : 0u;
+	if (FROM_BIG) hdr.x &= 0xFFFu;
+	uint32_t* s_bits = sh.dyn;
+	uint32_t* s_pos = sh.dyn + ((((c.L.total + 31u) >> 5) + 3u) & ~3u);
 	uint16_t* s_key = (uint16_t*)(s_pos + 2u * cap);
 	uint16_t* s_uctx = s_key + 2u * cap;
-	__shared__ unsigned long long s_sum[MGL_SIM_WAVES];
-	__shared__ uint32_t s_nu, s_many;
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
 	Changes ch;
 	ch.n_ins = hdr.x; ch.n_rem = hdr.y;
 	ch.ins_pos = s_pos; ch.rem_pos = s_pos + cap;
@@ -1142,7 +1157,13 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b
 	ch.cap = cap; ch.uctx_cap = 2 * cap;
 	ch.nbitwords = (c.L.total + 31u) >> 5;
 	ch.direct = 0; ch.dbg = nullptr; ch.diag = c.diag_stop; ch.overflow = false;
-	{
+	__syncthreads(); /* the previous neighbour of a striding workgroup is done with the LDS */
+	if (FROM_BIG) {
+		const uint16_t* ik = big.ins_key + (size_t)slot * big.cap; const uint32_t* ip = big.ins_pos + (size_t)slot * big.cap;
+		const uint16_t* rk = big.rem_key + (size_t)slot * big.cap; const uint32_t* rp = big.rem_pos + (size_t)slot * big.cap;
+		for (uint32_t e = threadIdx.x; e < ch.n_ins; e += blockDim.x) { s_key[e] = ik[e]; s_pos[e] = ip[e]; }
+		for (uint32_t e = threadIdx.x; e < ch.n_rem; e += blockDim.x) { s_key[cap + e] = rk[e]; s_pos[cap + e] = rp[e]; }
+	} else {
 		const uint16_t* gk = big.sim_keys + (size_t)j * (2u * cap);
 		const uint32_t* gp = big.sim_pos + (size_t)j * (2u * cap);
 		for (uint32_t e = threadIdx.x; e < ch.n_ins; e += blockDim.x) { s_key[e] = gk[e]; s_pos[e] = gp[e]; }
@@ -1152,10 +1173,10 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b
 	if (wid == 0) {
 		bool too_many = false;
 		const uint32_t nu = chain_list(ch, lane, &too_many);
-		if (lane == 0) { s_nu = nu; s_many = too_many ? 1u : 0u; }
+		if (lane == 0) { sh.nu_many[0] = nu; sh.nu_many[1] = too_many ? 1u : 0u; }
 	}
 	__syncthreads();
-	if (s_many) { /* more distinct contexts than the list holds: the second pass, as the second half would have done */
+	if (sh.nu_many[1]) { /* more distinct contexts than the list holds: the late second pass re-simulates it inline */
 		if (threadIdx.x == 0) {
 			const uint32_t slot2 = atomicAdd(todo_count, 1u);
 			todo[slot2] = j;
@@ -1164,15 +1185,37 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b
 		}
 		return;
 	}
-	if (c.diag_stop == 41) { if (threadIdx.x == 0) out.cost[j] = s_nu; return; } /* diagnostic: listing only */
-	const int64_t mine = chain_sim_contexts(b, ch, T, MGL_POS_INF, nullptr, lane, wid * 64u, 64u * MGL_SIM_WAVES, s_nu);
+	if (c.diag_stop == 41) { if (threadIdx.x == 0) out.cost[j] = sh.nu_many[0]; return; } /* diagnostic: listing only */
+	const int64_t mine = chain_sim_contexts(b, ch, sh.T, MGL_POS_INF, nullptr, lane, wid * 64u, 64u * MGL_SIM_WAVES, sh.nu_many[0]);
 	const uint64_t u = wave_sum64((uint64_t)mine);
-	if (lane == 0) s_sum[wid] = u;
+	if (lane == 0) sh.sum[wid] = u;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint64_t d = 0;
-		for (uint32_t w = 0; w < MGL_SIM_WAVES; w++) d += s_sum[w];
+		for (uint32_t w = 0; w < MGL_SIM_WAVES; w++) d += sh.sum[w];
 		const int64_t direct = (int64_t)((uint64_t)hdr.z | ((uint64_t)hdr.w << 32));
 		out.cost[j] = (uint64_t)((int64_t)ctl->rebuild_cost + (int64_t)d + direct);
+	}
+}
+/* list == nullptr: the regular launch, workgroup x = neighbour j_base + x with header sim_hdr.  list != nullptr: the
+ * second pass's neighbours (headers in sim_hdr2), a small grid striding over the list. */
+__global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
+                                                           uint32_t* todo, uint32_t* todo_count, const uint32_t* list, const uint32_t* list_count)
+{
+	if (list ? blockIdx.x >= *list_count : j_base + blockIdx.x >= j_end) return;
+	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
+	/* sized by the launch: one bit per context, then the two lists (positions, keys) and the context list */
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+	__shared__ unsigned long long s_sum[MGL_SIM_WAVES];
+	__shared__ uint32_t s_nm[2];
+	if (!list && big.sim_hdr[j_base + blockIdx.x].x == 0xFFFFFFFFu) return; /* before the table load: most launches of a bulk-free step's tail */
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
+	SimShared sh;
+	sh.T = T; sh.dyn = s_dyn; sh.sum = s_sum; sh.nu_many = s_nm;
+	if (list) {
+		const uint32_t n = *list_count;
+		for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) sim_one<true>(c, b, ctl, out, big, big.sim_hdr2, list[i], todo, todo_count, sh);
+	} else {
+		sim_one<false>(c, b, ctl, out, big, big.sim_hdr, j_base + blockIdx.x, todo, todo_count, sh);
 	}
 }

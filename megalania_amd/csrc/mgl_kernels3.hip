@@ -698,8 +698,9 @@ __device__ void step_end_body(Control* ctl, int lazy_best, uint32_t* counts, int
 			else if (ctl->accepted_flag) ctl->best_is_current = 0;
 		}
 		ctl->accepted_flag = 0; ctl->apply_failed = 0;
-		/* the per-step counters: kept for diagnostics in [4..7], cleared for the next step (saves a memset launch) */
-		for (int i = 0; i < 4; i++) { counts[4 + i] = counts[i]; counts[i] = 0; }
+		/* the per-step counters ([0] second-pass list, [1] last-resort list, [2] spill slots, [3] repair picks, [4] late second-pass list):
+		 * kept for diagnostics in [8..15], cleared for the next step (saves a memset launch) */
+		for (int i = 0; i < 8; i++) { counts[8 + i] = counts[i]; counts[i] = 0; }
 	}
 }
 __global__ void k_step_end(Control* ctl, int lazy_best, uint32_t* counts, int adaptive, int form_single)

@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 PROFILE_TAG = "r02"
 DEFAULT_K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}
 PREPARE_CAP = {"c1": 400, "c2": 1500, "c3": 6000, "c4": 1500, "c5": 2000}  # steps; the bulk phase normally ends well before
-DOMINANT = ("k_neighbours2<false, 1>", "k_neighbours2<false, 2>", "k_sim")
+DOMINANT = ("k_neighbours2", "k_sim")  # pick, walk, re-simulation, their one-kernel form and the second pass
 
 
 def cpu_model():
@@ -311,8 +311,8 @@ def main():
         evals_per_step = st["evaluations"] / max(1, st["steps"])
         pmc, pmc_path = load_pmc(cfg)
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_neighbours2<PICK> + k_neighbours2<REST> + k_sim (pick, window walk, chain re-simulation: the "
-                          "incremental neighbour evaluation; the step's other launches are the decision and the accept path)",
+                "kernel": "k_neighbours2<*> + k_sim: the incremental neighbour evaluation (pick, window walk, chain re-simulation, or their "
+                          "one-kernel form, + second pass); the step's other launches are the decision and the accept path",
                 "avg_launch_ms": nbr_ms, "launches_timed": launches,
                 "algorithmic_equiv_gbs": evals_per_step * b_eval / (nbr_ms * 1e-3) / 1e9 if nbr_ms > 0 else None,
                 "algorithmic_note": "evaluations/step x (N + 12 P) / time: what a streaming evaluator would move; the incremental "

@@ -195,7 +195,7 @@ def main():
                     help="search steps of the set-up phase (default: until the library's bulk phase is over, capped per config and at --prepare-seconds)")
     ap.add_argument("--prepare-seconds", type=float, default=90.0)
     ap.add_argument("--accept", default=None, choices=["auto", "single", "bulk"],
-                    help="accept mode of the warm-up and timed steps (default: auto; single for inputs above 32 MB)")
+                    help="accept mode of the warm-up and timed steps (default: single; the set-up phase always runs in auto)")
     ap.add_argument("--greedy-seed", type=int, default=-1, help="set-up from the greedy seed with this many candidates (default: 64 above 32 MB, else off)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -240,7 +240,10 @@ def main():
     props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
     big_input = n > (32 << 20)
     greedy = args.greedy_seed if args.greedy_seed >= 0 else (64 if big_input else 0)
-    accept = args.accept or ("single" if big_input else "auto")
+    # the timed steps are single-accept steps: once the bulk phase is over the library's AUTO mode still takes the odd
+    # block of bulk steps when improving neighbours pile up around its threshold, which would make a 20-step timed
+    # region a coin toss between two very different step costs; the long run's steady state is the single step
+    accept = args.accept or "single"
     sa = binding.SA(data, neighbours_per_step=K, seed=multi_gpu.chain_seed(1673551, rank), iters_per_epoch=n,
                     device=local_rank, timing=True, accept="auto", **props)
     comm = None

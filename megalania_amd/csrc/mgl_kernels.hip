@@ -164,7 +164,10 @@ __device__ __forceinline__ uint32_t nx_lower_bound(const uint16_t* a, uint32_t l
  * packet at the walk's state, cost each from the adapted model (cost = perplexity/length,
  * :115-116), keep the k best.  Order-independent ("canonical") selection: better = lower
  * cost, then later in the reference's enumeration order (the reference's `<=`, :89).
- * lencost: LDS scratch, 2 x 272 u32. */
+ * lencost: LDS scratch, 2 x 272 u32.
+ * W: entries a lane takes per trip through the exact-length sources (4 where registers allow: the pick kernel; 1 in the
+ * one-kernel form, which has none to spare). */
+template <int W>
 __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_t* probs, const uint16_t* T,
                           uint32_t* lencost, mgl_pk incumbent, uint32_t lane)
 {
@@ -482,7 +485,7 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 	 * length per source the pruning bound is one distance threshold, recomputed only when the K-th best moves: an
 	 * entry at distance >= dthr cannot qualify at length D or shorter (hdr + cheapest length price up to D +
 	 * sufmin[slot] >= lim * D, a true lower bound), and the scan of the source ends at the first such entry.  The
-	 * scan is memory latency bound, so a lane takes four consecutive entries per trip (256 per wavefront: one
+	 * scan is memory latency bound, so a lane takes W consecutive entries per trip (W = 4: 256 per wavefront, one
 	 * 16-byte and one 4-byte load) and filters them with a subtraction and two compares each. */
 	for (uint32_t D = 7; D >= 2; D--) {
 		if (c.diag_stop == 38 && D < 4) break;
@@ -518,22 +521,22 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 				dthr = sl < 4u ? sl : ((2u | (sl & 1u)) << ((sl >> 1) - 1u)); /* first distance of that slot */
 			}
 		};
-		/* entries hb + 4 lane + r, r = 0..3 (r = 0 nearest): array indices top - 1 - e, i.e. the four words at
-		 * top - 4 - hb - 4 lane, the nearest last */
-		auto load4 = [&](uint32_t hb, uint32_t qv[4], uint32_t& yv) {
-			const uint32_t e0 = hb + 4u * lane;
-			if (e0 + 3u < cnt) {
+		/* entries hb + W lane + r, r = 0..W-1 (r = 0 nearest): array indices top - 1 - e, i.e. the W words at
+		 * top - W - hb - W lane, the nearest last */
+		auto loadw = [&](uint32_t hb, uint32_t qv[W], uint32_t& yv) {
+			const uint32_t e0 = hb + (uint32_t)W * lane;
+			if (W == 4 && e0 + 3u < cnt) {
 				const uint32_t base = top - 4u - e0;
 				uint4 qq;
 				__builtin_memcpy(&qq, spos + base, 16);
-				qv[0] = qq.w; qv[1] = qq.z; qv[2] = qq.y; qv[3] = qq.x;
+				qv[0] = qq.w; qv[1 % W] = qq.z; qv[2 % W] = qq.y; qv[3 % W] = qq.x;
 				uint32_t yy;
 				__builtin_memcpy(&yy, snxb + base, 4);
 				yv = __builtin_bswap32(yy); /* byte r of yv = entry r */
 			} else {
 				yv = 0;
 #pragma unroll
-				for (uint32_t r = 0; r < 4; r++) {
+				for (uint32_t r = 0; r < (uint32_t)W; r++) {
 					const bool in = e0 + r < cnt;
 					const uint32_t idx = in ? top - 1u - (e0 + r) : top - 1u;
 					qv[r] = in ? spos[idx] : pos; /* distance "-1": never passes the filter */
@@ -542,27 +545,36 @@ __device__ void topk_find(TopK& t, const DevCtx& c, const Walk& w, const uint16_
 			}
 		};
 		refresh_threshold();
-		uint32_t qa[4], qb[4] = { 0, 0, 0, 0 }, ya, yb = 0;
-		load4(0, qa, ya);
-		for (uint32_t hb = 0; hb < cnt; hb += 256) {
-			if (hb + 256u < cnt) load4(hb + 256u, qb, yb); /* the next trip, in flight */
+		uint32_t qa[W], qb[W], ya, yb = 0;
+#pragma unroll
+		for (uint32_t r = 0; r < (uint32_t)W; r++) qb[r] = 0;
+		loadw(0, qa, ya);
+		for (uint32_t hb = 0; hb < cnt; hb += 64u * W) {
+			if (hb + 64u * W < cnt) loadw(hb + 64u * W, qb, yb); /* the next trip, in flight */
 			if (lim_seen != lim32) refresh_threshold();
 			/* lane 0's first entry is the nearest of this trip */
 			if (pos - rdlane(qa[0], 0) - 1u >= dthr) break;
-			bool pr[4];
+			uint32_t prmask = 0; /* bit r: entry r of this lane passes the filter */
 #pragma unroll
-			for (uint32_t r = 0; r < 4; r++) {
+			for (uint32_t r = 0; r < (uint32_t)W; r++) {
 				const uint32_t d = pos - qa[r] - 1u; /* out-of-range slots hold q = pos: d = 0xFFFFFFFF */
 				/* byte D equal: the match goes on: priced from the next source up */
-				pr[r] = ((ya >> (8u * r)) & 0xFFu) != xb && d < dthr && d != 0xFFFFFFFFu;
+				const bool p = ((ya >> (8u * r)) & 0xFFu) != xb && d < dthr && d != 0xFFFFFFFFu;
+				prmask |= (p ? 1u : 0u) << r;
+			}
+			if (c.diag_stop == 39) prmask = 0; /* diagnostic: the filter alone */
+			/* one copy of the pricing code: the (rare) survivors of the W entries take turns */
+			for (uint32_t r = 0; r < (uint32_t)W && __ballot(prmask != 0); r++) {
+				const bool p = (prmask >> r) & 1u;
+				if (!__ballot(p)) continue;
+				uint32_t q_r = qa[0];
+#pragma unroll
+				for (uint32_t k = 1; k < (uint32_t)W; k++) q_r = r == k ? qa[k] : q_r;
+				price_hits(q_r, hitlen, p);
+				prmask &= ~(1u << r);
 			}
 #pragma unroll
-			for (uint32_t r = 0; r < 4; r++) {
-				if (!__ballot(pr[r]) || c.diag_stop == 39) continue; /* 39: diagnostic, the filter alone */
-				price_hits(qa[r], hitlen, pr[r]);
-			}
-#pragma unroll
-			for (uint32_t r = 0; r < 4; r++) qa[r] = qb[r];
+			for (uint32_t r = 0; r < (uint32_t)W; r++) qa[r] = qb[r];
 			ya = yb;
 		}
 	}
@@ -726,11 +738,12 @@ struct NbrRng { uint64_t key; uint32_t n; };
 __device__ __forceinline__ uint32_t nbr_draw(NbrRng& r) { return mgl_rng_draw(r.key, r.n++); }
 
 /* packet_slab_neighbour.c:56-72 with the canonical top-K order */
+template <int W>
 __device__ bool pick_from_top_k(const DevCtx& c, const Walk& w, const uint16_t* probs, const uint16_t* T, uint32_t* lencost,
                                 mgl_pk incumbent, bool best, NbrRng& rng, uint32_t lane, mgl_pk* picked)
 {
 	TopK t;
-	topk_find(t, c, w, probs, T, lencost, incumbent, lane);
+	topk_find<W>(t, c, w, probs, T, lencost, incumbent, lane);
 	const uint32_t count = t.count;
 	if (count == 0) return false;
 	uint32_t choice = nbr_draw(rng) % count; /* :48-54 max of 8 draws */
@@ -895,7 +908,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 	}
 	if (!mutated) {
 		mgl_pk picked;
-		if (!pick_from_top_k(c, w, probs, T, lencost, first, false, rng, lane, &picked)) {
+		if (!pick_from_top_k<1>(c, w, probs, T, lencost, first, false, rng, lane, &picked)) {
 			if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_NONE; }
 			return;
 		}
@@ -930,7 +943,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 			if (!ok) {
 				const bool best = (nbr_draw(rng) % 4u) == 0;
 				mgl_pk picked;
-				if (pick_from_top_k(c, w, probs, T, lencost, pk, best, rng, lane, &picked)) pk = picked;
+				if (pick_from_top_k<1>(c, w, probs, T, lencost, pk, best, rng, lane, &picked)) pk = picked;
 			}
 		}
 		if (pk != old) {
@@ -1038,7 +1051,7 @@ __global__ void __launch_bounds__(64) k_topk_probe(DevCtx c, BaseView b, uint32_
 	}
 	walk_window(w, c, b.slab, lane);
 	TopK t;
-	topk_find(t, c, w, probs, T, lencost, walk_slab_at(w, position), lane);
+	topk_find<4>(t, c, w, probs, T, lencost, walk_slab_at(w, position), lane);
 	if (lane < t.count) {
 		const uint32_t o = t.count - 1 - lane; /* worst first */
 		out_pk[o] = topk_packet(t.key, position);

@@ -903,7 +903,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			walk_from_state(tw, nb);
 			walk_window(tw, c, b.slab, lane);
 			mgl_pk picked;
-			const bool ok = pick_from_top_k(c, tw, probs, T, lencost, pick_inc, pick_best, rng, lane, &picked);
+			const bool ok = pick_from_top_k<(MODE == MGL_NBR_PICK ? 4 : 1)>(c, tw, probs, T, lencost, pick_inc, pick_best, rng, lane, &picked);
 			if (MODE == MGL_NBR_PICK) {
 				if (lane == 0) pickrec[j] = make_uint4((uint32_t)picked, (uint32_t)(picked >> 32), rng.n, ok ? 1u : 0u);
 				return;
@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 }
 
 template <bool BIG, int MODE>
-__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? MGL_NBR_WAVES_PER_SIMD : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
+__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? (BIG ? 1 : MGL_NBR_WAVES_PER_SIMD) : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
                                                      BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate)

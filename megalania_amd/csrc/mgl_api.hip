@@ -353,8 +353,10 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	const uint32_t bigneed = (sa->big.slots + sa->waves_per_block2 - 1) / sa->waves_per_block2; /* a slot per neighbour: none is dropped */
 	const uint32_t bigblocks = bigneed < 1024u ? bigneed : 1024u; /* the kernel strides over its list */
 	BigScratch big_now = sa->big;
+	big_now.lds_cache = 1u;
+	const uint32_t big_lds = sa->nbr2_lds + 12u * MGL_BIG_CAP; /* + a copy of both lists for the re-simulations */
 	if (!split_now || getenv("MGL_BIG_INLINE_SIM")) big_now.sim_hdr2 = nullptr; /* the one-kernel form has no k_sim launch to hand over to */
-	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
 	                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
 	if (split_now) {
@@ -365,8 +367,8 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 		/* what k_sim (either launch) could not take: a late second pass that re-simulates inline */
 		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 		BigScratch late = sa->big;
-		late.todo_in = sa->d_todo3; late.todo_in_count = sa->d_counts + 4; late.sim_hdr2 = nullptr;
-		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 64u ? bigblocks : 64u), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
+		late.todo_in = sa->d_todo3; late.todo_in_count = sa->d_counts + 4; late.sim_hdr2 = nullptr; late.lds_cache = 1u;
+		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 64u ? bigblocks : 64u), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
 		                   (unsigned long long*)nullptr, late, sa->d_pickrec, 0u, K, sa->d_pickstate);
 	}
@@ -417,7 +419,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
+	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->big.sim_slot2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
 	dfree(sa->ab.span_pos); dfree(sa->ab.span_ev); dfree(sa->ab.jobs_b); dfree(sa->ab.jobs_c);
@@ -732,7 +734,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_PICK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_REST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
-		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sa->nbr2_lds + 12u * MGL_BIG_CAP)));
 		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
 		HIPCHK(hipMalloc(&sa->d_pickstate, sizeof(uint4) * 2 * K));
 		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;
@@ -744,6 +746,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&g.sim_pos, sizeof(uint32_t) * 2u * sa->chg_cap * (size_t)K));
 			HIPCHK(hipMemset(g.sim_hdr, 0xFF, sizeof(uint4) * (size_t)K));
 			HIPCHK(hipMalloc(&g.sim_hdr2, sizeof(uint4) * (size_t)K));
+			HIPCHK(hipMalloc(&g.sim_slot2, sizeof(uint32_t) * (size_t)K));
 			HIPCHK(hipMemset(g.sim_hdr2, 0xFF, sizeof(uint4) * (size_t)K));
 		}
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
@@ -767,7 +770,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			if (n > (1u << 20)) best_w = 1;
 			if (sa->pick_waves == 0 || 4096u + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = best_w;
 		}
-		HIPCHK(hipFuncSetAttribute((const void*)k_sim, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+		HIPCHK(hipFuncSetAttribute((const void*)k_sim, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build_end, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}

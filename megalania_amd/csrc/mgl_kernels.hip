@@ -779,22 +779,50 @@ __device__ __forceinline__ mgl_pk journal_or_base(const Journal& jn, const mgl_p
  * mutated one (the incremental kernel stops its two-pointer walk there).  The
  * full-walk engine has walked to the end of the file, so it finds the point afterwards from the
  * journal.  `st` = walk state at the target (uniform). */
-struct WinInfo { uint32_t end, soft; };
+/* n literal transitions of the ctx_state automaton (3 reach 0 from anywhere) */
+__device__ __forceinline__ uint32_t lit_steps_(uint32_t s, uint32_t n)
+{
+	if (n > 3) n = 3;
+	for (uint32_t i = 0; i < n; i++) s = mgl_next_ctx_state(s, MGL_LITERAL);
+	return s;
+}
+struct WinInfo { uint32_t end, soft, n_ins, n_rem, walked; };
+/* events of one packet (mgl_plan_packet's nev: independent of the bytes) */
+__device__ __forceinline__ uint32_t packet_events(const DevCtx& c, const mgl_wstate& st, mgl_pk pk)
+{
+	mgl_plan pl;
+	mgl_plan_packet(&c.L, &st, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), 0u, 0u, 0u, &pl);
+	return pl.nev;
+}
 __device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, const Journal& jn, mgl_wstate st, uint32_t rep_free, uint32_t lane)
 {
 	mgl_wstate nb = st, bs = st;
-	uint32_t count = 0, wsoft = 0xFFFFFFFFu, taint = 0xFu, dep = 0u, wend;
+	uint32_t count = 0, wsoft = 0xFFFFFFFFu, taint = 0xFu, dep = 0u, wend = c.n, n_ins = 0, n_rem = 0, walked = 0;
 	bool first = true;
 	for (;;) {
 		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state) {
 			if (wsoft == 0xFFFFFFFFu && nb.pos >= rep_free) wsoft = nb.pos;
 			if (nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] && nb.dists[3] == bs.dists[3]) { wend = nb.pos; break; }
+			if (nb.ctx_state < 7u && nb.pos < c.n) {
+				/* plain literals up to the base's next non-literal packet: skipped, not visited (the incremental kernel's jump) */
+				uint32_t sx = nb.pos;
+				while (sx < c.n && mgl_pk_type(uni64(slab[sx])) == MGL_LITERAL) sx++;
+				if (sx > nb.pos) {
+					const uint32_t cs = lit_steps_(nb.ctx_state, sx - nb.pos);
+					nb.pos = bs.pos = sx; nb.ctx_state = bs.ctx_state = cs;
+					count = 8;
+					continue;
+				}
+			}
 		}
 		if (nb.pos >= c.n && bs.pos >= c.n) { wend = c.n; break; }
+		if (walked > 512u) break; /* MGL_MAX_WALK */
 		if (nb.pos <= bs.pos && nb.pos < c.n) {
 			if (!first && count < 8) count++;
 			first = false;
-			const mgl_pk pk = uni64(journal_or_base(jn, slab, nb.pos, lane));
+			walked++;
+			const uint32_t p = nb.pos;
+			const mgl_pk pk = uni64(journal_or_base(jn, slab, p, lane));
 			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk);
 			if (wsoft == 0xFFFFFFFFu) {
 				if (ntype == MGL_SHORT_REP) dep |= taint & 1u;
@@ -802,13 +830,33 @@ __device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, 
 			}
 			if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;
 			else if (ntype == MGL_LONG_REP) taint = (taint & ~((2u << ndist) - 1u)) | ((taint & ((1u << ndist) - 1u)) << 1) | ((taint >> ndist) & 1u);
+			/* identical coding of the base packet at the same position cancels (the rule of the incremental kernel) */
+			const bool paired = bs.pos == p;
+			mgl_pk bpk = pk;
+			bool cancelled = false;
+			if (paired) {
+				bpk = uni64(slab[p]);
+				cancelled = bpk == pk && nb.ctx_state == bs.ctx_state;
+				if (cancelled && ntype == MGL_LITERAL && nb.ctx_state >= 7) {
+					const uint32_t mn = nb.dists[0] < p ? c.data[p - nb.dists[0] - 1] : 0u;
+					const uint32_t mb = bs.dists[0] < p ? c.data[p - bs.dists[0] - 1] : 0u;
+					cancelled = mn == mb;
+				}
+			}
+			if (!cancelled) {
+				n_ins += packet_events(c, nb, pk);
+				if (paired) n_rem += packet_events(c, bs, bpk);
+			}
+			if (paired) mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
 			mgl_advance(&nb, ntype, ndist, mgl_pk_len(pk));
 		} else {
 			const mgl_pk pk = uni64(slab[bs.pos]);
+			n_rem += packet_events(c, bs, pk);
 			mgl_advance(&bs, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk));
 		}
 	}
 	WinInfo wi;
+	wi.n_ins = n_ins; wi.n_rem = n_rem; wi.walked = walked;
 	wi.end = wend;
 	wi.soft = (wsoft < wend ? wsoft : wend) | (dep << 31);
 	return wi;
@@ -918,7 +966,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 	walk_packet<true>(w, c, probs, T, mgl_pk_type(m_first), mgl_pk_dist(m_first), mgl_pk_len(m_first), lane); /* :169 */
 
 	/* repair_remaining_packets, packet_slab_neighbour.c:82-117 */
-	uint32_t count = 0, guard = 0;
+	uint32_t count = 0, guard = 0, npicks = 0;
 	while (w.st.pos < c.n && !jn.overflow) {
 		if (++guard > c.n) break;
 		count++;
@@ -941,6 +989,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 			for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, w, idx, len, lane); }
 			pk = mgl_pack(MGL_LONG_REP, idx, len);
 			if (!ok) {
+				npicks++;
 				const bool best = (nbr_draw(rng) % 4u) == 0;
 				mgl_pk picked;
 				if (pick_from_top_k<1>(c, w, probs, T, lencost, pk, best, rng, lane, &picked)) pk = picked;
@@ -961,6 +1010,10 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 	}
 	const WinInfo wi = window_end_from_journal(c, b.slab, jn, st_target, ctl->rep_free_from, lane);
 	const uint32_t wend = wi.end;
+	if (wi.n_ins > 4096u || wi.n_rem > 4096u || wi.walked > 512u || npicks > 8u) { /* MGL_BIG_CAP / MGL_MAX_WALK / MGL_MAX_REPAIR_PICKS: what the incremental engine's lists hold, its walk visits, its repair picks */
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
+		return;
+	}
 	/* journal out: entries whose final value equals the base value are dropped */
 	uint32_t nd = 0;
 	for (uint32_t i = 0; i < jn.count; i++) {

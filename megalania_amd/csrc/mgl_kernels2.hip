@@ -246,6 +246,7 @@ struct Changes {
 	unsigned long long* dbg; /* diagnostic counters (MGL_F_PROFILE), else nullptr */
 	uint32_t diag;
 	bool overflow;
+	bool list_full;        /* overflow because a list reached its capacity (as opposed to any other reason) */
 };
 
 /* append the events of one planned packet to the inserted (INS) or removed list */
@@ -253,7 +254,7 @@ template <bool INS>
 __device__ __forceinline__ void changes_add(Changes& ch, const mgl_plan& pl, uint32_t pos, uint32_t lane)
 {
 	uint32_t& n = INS ? ch.n_ins : ch.n_rem;
-	if (n + pl.nev > ch.cap) { ch.overflow = true; return; }
+	if (n + pl.nev > ch.cap) { ch.overflow = true; ch.list_full = true; return; }
 	if (lane < pl.nev) {
 		uint32_t ctx, bit;
 		mgl_plan_event(&pl, lane, &ctx, &bit);
@@ -539,7 +540,7 @@ __device__ __forceinline__ uint32_t literal_run_events(const DevCtx& c, Changes&
 	if (run < 2u) return 0;
 	const uint32_t take = run < 7u ? run : 7u;
 	uint32_t& n = INS ? ch.n_ins : ch.n_rem;
-	if (n + 9u * take > ch.cap) { ch.overflow = true; return take; }
+	if (n + 9u * take > ch.cap) { ch.overflow = true; ch.list_full = true; return take; }
 	const uint32_t i = lane / 9u, slot = lane - i * 9u;
 	const uint32_t p = st.pos + i;
 	const bool active = i < take;
@@ -651,6 +652,8 @@ struct BigScratch {
 	uint32_t chg_cap; /* events per first-pass list (MGL_CHG_CAP, more when a step has few neighbours and LDS to spare) */
 	uint4* sim_hdr;
 	uint4* sim_hdr2; /* the same for the second pass's neighbours (k_sim's second launch); nullptr: the second pass re-simulates inline */
+	uint32_t* sim_slot2; /* per neighbour: the scratch slot its lists sit in */
+	uint32_t lds_cache; /* second pass: 12 * MGL_BIG_CAP bytes of LDS behind the wavefront's area hold a copy of the lists during a re-simulation */
 	uint16_t* sim_keys; /* per neighbour: ins_key[chg_cap] | rem_key[chg_cap] */
 	uint32_t* sim_pos;  /* per neighbour: ins_pos[chg_cap] | rem_pos[chg_cap] */
 };
@@ -663,7 +666,7 @@ struct BigScratch {
  *                 chain re-simulation.  A repair that needs another top-K pick (rare) hands the
  *                 neighbour to the next pass;
  *   MGL_NBR_FULL  the whole thing in one kernel (the BIG second pass, which starts from scratch). */
-#define MGL_SIM2_CAP 2048u /* events per list k_sim's second launch takes (the second pass's neighbours) */
+#define MGL_SIM2_CAP 4096u /* events per list k_sim's second launch takes (the second pass's neighbours) */
 #define MGL_NBR_FULL 0
 #define MGL_NBR_PICK 1
 #define MGL_NBR_REST 2
@@ -720,7 +723,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		ch.uctx = big.uctx + (size_t)slot * big.uctx_cap;
 		ch.cap = big.cap; ch.uctx_cap = big.uctx_cap;
 	}
-	ch.n_ins = ch.n_rem = 0; ch.direct = 0; ch.overflow = false;
+	ch.n_ins = ch.n_rem = 0; ch.direct = 0; ch.overflow = false; ch.list_full = false;
 	bool too_many = false;
 	bool spilled = BIG;
 	const bool spilled_lds = false; /* BIG: the lists live in this neighbour's global scratch slot from the start */
@@ -815,7 +818,8 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	uint32_t sim_limit = MGL_POS_INF;
 	bool sim_overlay = false;
 	int64_t delta = 0;
-	bool generate_failed = false, sim_deferred = false;
+	bool generate_failed = false, sim_deferred = false, walk_long = false;
+	uint32_t npicks = 0; /* repair picks of this neighbour */
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
 	uint32_t wend = 0; /* where the two walks meet again: the end of this neighbour's window */
@@ -874,7 +878,10 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			/* the second pass hands over its FINAL re-simulation too: k_sim's second launch reads the lists straight from this
 			 * neighbour's scratch slot into LDS and puts two wavefronts on them (here they sit in global memory in front of one
 			 * wavefront: the long-list neighbours were the slowest of the pass) */
-			if (lane == 0) big.sim_hdr2[j] = make_uint4(ch.n_ins | (slot << 12), ch.n_rem, (uint32_t)(uint64_t)ch.direct, (uint32_t)((uint64_t)ch.direct >> 32));
+			if (lane == 0) {
+				big.sim_slot2[j] = slot;
+				big.sim_hdr2[j] = make_uint4(ch.n_ins, ch.n_rem, (uint32_t)(uint64_t)ch.direct, (uint32_t)((uint64_t)ch.direct >> 32));
+			}
 			sim_deferred = true;
 			phase = P_OUT;
 			continue;
@@ -893,7 +900,21 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			continue;
 		}
 		if (MODE == MGL_NBR_FULL && phase == P_SIM) {
-			const int64_t r = chain_sim(b, ch, T, sim_limit, (MODE != MGL_NBR_REST && sim_overlay) ? probs : nullptr, lane, &too_many);
+			int64_t r;
+			if (BIG && big.lds_cache && ch.n_ins <= MGL_BIG_CAP && ch.n_rem <= MGL_BIG_CAP) {
+				/* the second pass keeps its lists in global memory; a re-simulation scans them once per touched context,
+				 * so it works on a copy in LDS (behind this wavefront's regular area: the second pass's launch reserves it) */
+				uint32_t* cp = (uint32_t*)(mine + per_wave_bytes);
+				Changes cl = ch;
+				cl.ins_pos = cp; cl.rem_pos = cp + MGL_BIG_CAP;
+				cl.ins_key = (uint16_t*)(cp + 2u * MGL_BIG_CAP); cl.rem_key = cl.ins_key + MGL_BIG_CAP;
+				for (uint32_t e = lane; e < ch.n_ins; e += 64) { cl.ins_pos[e] = ch.ins_pos[e]; cl.ins_key[e] = ch.ins_key[e]; }
+				for (uint32_t e = lane; e < ch.n_rem; e += 64) { cl.rem_pos[e] = ch.rem_pos[e]; cl.rem_key[e] = ch.rem_key[e]; }
+				wave_sync();
+				r = chain_sim(b, cl, T, sim_limit, sim_overlay ? probs : nullptr, lane, &too_many);
+			} else {
+				r = chain_sim(b, ch, T, sim_limit, (MODE != MGL_NBR_REST && sim_overlay) ? probs : nullptr, lane, &too_many);
+			}
 			wave_sync();
 			if (too_many) { phase = P_OUT; continue; }
 			if (sim_overlay) phase = P_TOPK;
@@ -945,6 +966,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 						}
 					}
 				}
+				if (walked > MGL_MAX_WALK && !have_pick) { walk_long = true; break; }
 				if ((have_pick || nb.pos <= bs.pos) && nb.pos < c.n) {
 					/* ---- next neighbour packet: repair rules of packet_slab_neighbour.c:82-117 */
 					const uint32_t p = nb.pos;
@@ -973,6 +995,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 							for (uint32_t i = 0; i < 4 && !ok; i++) { idx = i; ok = long_rep_ok(c, tw, idx, len, lane); }
 							pk = mgl_pack(MGL_LONG_REP, idx, len);
 							if (!ok) {
+								if (++npicks > MGL_MAX_REPAIR_PICKS) { walk_long = true; break; }
 								pick_best = (nbr_draw(rng) % 4u) == 0;
 								/* the model at p needs every base packet that starts before p priced in */
 								while (bs.pos < p && !ch.overflow) {
@@ -1044,6 +1067,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
 				}
 			}
+			if (walk_long) { phase = P_OUT; continue; }
 			if (request_pick) { phase = P_MODEL; continue; }
 			prof_mark(prof, 3, lane); /* window walk */
 			if (c.diag_stop == 4) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = ch.n_ins + ch.n_rem; } return; }
@@ -1060,6 +1084,12 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		return;
 	}
 	if (jn.overflow) { /* same rule as the full-walk path and the oracle: dropped */
+		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
+		return;
+	}
+	if (walk_long || (ch.list_full && ch.cap == big.cap && !jn.overflow)) {
+		/* more inserted or removed events than the second pass's lists hold (MGL_BIG_CAP), or more than MGL_MAX_WALK packets
+		 * visited before the walks met again: dropped, like a neighbour with too long a journal; the oracle counts the same */
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = walked; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
 		return;
 	}
@@ -1139,11 +1169,10 @@ template <bool FROM_BIG>
 __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control* ctl, const NbrOut& out, const BigScratch& big, const uint4* hdrs,
                                         uint32_t j, uint32_t* todo, uint32_t* todo_count, const SimShared& sh)
 {
-	uint4 hdr = hdrs[j];
+	const uint4 hdr = hdrs[j];
 	if (hdr.x == 0xFFFFFFFFu) return; /* failed, dropped or handed on: its cost is written (uniform over the workgroup) */
 	const uint32_t cap = FROM_BIG ? MGL_SIM2_CAP : big.chg_cap;
-	const uint32_t slot = FROM_BIG ? hdr.x >> 12 : 0u;
-	if (FROM_BIG) hdr.x &= 0xFFFu;
+	const uint32_t slot = FROM_BIG ? big.sim_slot2[j] : 0u;
 	uint32_t* s_bits = sh.dyn;
 	uint32_t* s_pos = sh.dyn + ((((c.L.total + 31u) >> 5) + 3u) & ~3u);
 	uint16_t* s_key = (uint16_t*)(s_pos + 2u * cap);
@@ -1156,7 +1185,7 @@ __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control
 	ch.uctx = s_uctx; ch.ctxbits = s_bits;
 	ch.cap = cap; ch.uctx_cap = 2 * cap;
 	ch.nbitwords = (c.L.total + 31u) >> 5;
-	ch.direct = 0; ch.dbg = nullptr; ch.diag = c.diag_stop; ch.overflow = false;
+	ch.direct = 0; ch.dbg = nullptr; ch.diag = c.diag_stop; ch.overflow = false; ch.list_full = false;
 	__syncthreads(); /* the previous neighbour of a striding workgroup is done with the LDS */
 	if (FROM_BIG) {
 		const uint16_t* ik = big.ins_key + (size_t)slot * big.cap; const uint32_t* ip = big.ins_pos + (size_t)slot * big.cap;

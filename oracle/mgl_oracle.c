@@ -635,6 +635,7 @@ typedef struct {
 	void* rng_ud;
 	int topk_mode;
 	uint16_t* scratch;
+	size_t repair_picks; /* LONG_REPs of the repair that no rep distance fitted: each costs a top-K query */
 } gen_env;
 
 /* ref: packet_slab_neighbour.c:48-54 */
@@ -722,6 +723,7 @@ static void repair(gen_env* g, orc_state* st, orc_sink* s, orc_packet* slab, jou
 			while (!long_rep_ok(c, st, *pk) && idx < 4) { pk->dist = idx; idx++; }
 			if (!long_rep_ok(c, st, *pk)) {
 				int best = (g->rng(g->rng_ud) % 4 == 0);
+				g->repair_picks++;
 				pick_from_top_k(g, st, slab, best);
 			}
 		}
@@ -770,7 +772,7 @@ int orc_sa_iters(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_i
                  uint64_t* trace, uint64_t* undo_total)
 {
 	uint16_t* probs = (uint16_t*)malloc(sizeof(uint16_t) * c->L.total * 2);
-	gen_env g = { c, libc_rng, NULL, ORC_TOPK_REF, probs + c->L.total };
+	gen_env g = { c, libc_rng, NULL, ORC_TOPK_REF, probs + c->L.total, 0 };
 	journal jn = { 0 };
 	uint64_t cur = *cur_io, best_cost = *best_cost_io, undos = 0;
 	size_t t = 0;
@@ -804,6 +806,9 @@ int orc_sa_iters(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_i
 
 /* ---------------------------------------------------------------- batched semantics */
 #define ORC_MAX_JOURNAL 64
+#define ORC_MAX_EVENTS 4096
+#define ORC_MAX_REPAIR_PICKS 8 /* top-K picks the repair of one neighbour may need (invalid LONG_REPs, packet_slab_neighbour.c:99-109) */
+#define ORC_MAX_WALK 512 /* neighbour packets the device's two-pointer walk visits before it gives a neighbour up */
 static uint64_t mix64(uint64_t z)
 {
 	z += 0x9E3779B97F4A7C15ull;
@@ -867,10 +872,27 @@ static orc_packet base_at(const orc_packet* slab, const journal* jn, size_t p)
  * still differ there, but nothing from there on reads them, so a second neighbour may start there provided
  * it is self-contained.  dep: the neighbour is NOT self-contained -- some SHORT_REP / LONG_REP packet of its
  * parse inside the window reads a rep distance that was pushed before the window. */
-typedef struct { size_t end, soft_end; int dep; } window_info;
+typedef struct { size_t end, soft_end; int dep; size_t n_ins, n_rem, walked; } window_info;
+/* events (coded bits with a probability context) of one packet: 1 + 8 for a literal, 4 for a short rep, header +
+ * length (+ slot + low distance bits through a reverse tree or the align tree) otherwise; direct bits are not events */
+static size_t packet_events(const wstate* w, orc_packet pk)
+{
+	(void)w;
+	if (pk.type == ORC_LITERAL) return 9;
+	if (pk.type == ORC_SHORT_REP) return 4;
+	const unsigned l = pk.len - 2u;
+	const size_t lenbits = l < 8 ? 4 : (l < 16 ? 5 : 10);
+	if (pk.type == ORC_LONG_REP) return (pk.dist < 2 ? 4 : 5) + lenbits;
+	size_t tail = 0;
+	if (pk.dist >= 4) {
+		const unsigned nlow = (32u - (unsigned)__builtin_clz(pk.dist)) - 2u, slot = nlow * 2u + (pk.dist >> nlow);
+		tail = slot < 14 ? nlow : 4;
+	}
+	return 2 + lenbits + 6 + tail;
+}
 static window_info window_end(const orc_ctx* c, const orc_packet* slab, const journal* jn, size_t target, size_t rep_free_from)
 {
-	window_info wi = { c->n, (size_t)-1, 0 };
+	window_info wi = { c->n, (size_t)-1, 0, 0, 0, 0 };
 	wstate bs = { 0, 0, { 0, 0, 0, 0 } };
 	while (bs.pos < target) wstate_advance(&bs, base_at(slab, jn, bs.pos));
 	wstate nb = bs;
@@ -880,12 +902,29 @@ static window_info window_end(const orc_ctx* c, const orc_packet* slab, const jo
 		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state) {
 			if (wi.soft_end == (size_t)-1 && nb.pos >= rep_free_from) wi.soft_end = nb.pos;
 			if (wstate_same(&nb, &bs)) { wi.end = nb.pos; break; }
+			if (nb.ctx_state < 7 && nb.pos < c->n) {
+				/* plain literals up to the base's next non-literal packet are coded identically in both walks: the device
+				 * skips them in one jump (they do not count as visited) */
+				size_t sx = nb.pos;
+				while (sx < c->n && base_at(slab, jn, sx).type == ORC_LITERAL) sx++;
+				if (sx > nb.pos) {
+					const size_t k = sx - nb.pos;
+					for (size_t i = 0; i < (k < 3 ? k : 3); i++) nb.ctx_state = next_ctx_state(nb.ctx_state, ORC_LITERAL);
+					bs.ctx_state = nb.ctx_state;
+					nb.pos = bs.pos = sx;
+					count = 8;
+					continue;
+				}
+			}
 		}
 		if (nb.pos >= c->n && bs.pos >= c->n) { wi.end = c->n; break; }
+		if (wi.walked > ORC_MAX_WALK) break; /* given up: the caller drops it */
 		if (nb.pos <= bs.pos && nb.pos < c->n) {
 			if (!first && count < 8) count++;
 			first = 0;
-			const orc_packet pk = slab[nb.pos];
+			wi.walked++;
+			const size_t p = nb.pos;
+			const orc_packet pk = slab[p];
 			if (wi.soft_end == (size_t)-1) { /* inside the (soft) window: what the packet reads */
 				if (pk.type == ORC_SHORT_REP) wi.dep |= taint & 1u;
 				else if (pk.type == ORC_LONG_REP) wi.dep |= (taint >> pk.dist) & 1u;
@@ -895,9 +934,30 @@ static window_info window_end(const orc_ctx* c, const orc_packet* slab, const jo
 				const unsigned k = pk.dist, bit = (taint >> k) & 1u;
 				taint = (taint & ~((2u << k) - 1u)) | ((taint & ((1u << k) - 1u)) << 1) | bit;
 			}
+			/* the base packet at the same position: identical coding cancels (same packet, same ctx_state and -- for a
+			 * literal after a match -- the same byte at rep distance 0); otherwise its events go and the neighbour's come */
+			const int paired = bs.pos == p;
+			orc_packet bpk = pk;
+			int cancelled = 0;
+			if (paired) {
+				bpk = base_at(slab, jn, p);
+				cancelled = pk_eq(pk, bpk) && nb.ctx_state == bs.ctx_state;
+				if (cancelled && pk.type == ORC_LITERAL && nb.ctx_state >= 7) {
+					const unsigned mn = nb.dists[0] < p ? c->data[p - nb.dists[0] - 1] : 0u;
+					const unsigned mb = bs.dists[0] < p ? c->data[p - bs.dists[0] - 1] : 0u;
+					cancelled = mn == mb;
+				}
+			}
+			if (!cancelled) {
+				wi.n_ins += packet_events(&nb, pk);
+				if (paired) wi.n_rem += packet_events(&bs, bpk);
+			}
+			if (paired) wstate_advance(&bs, bpk);
 			wstate_advance(&nb, pk);
 		} else {
-			wstate_advance(&bs, base_at(slab, jn, bs.pos));
+			const orc_packet bpk = base_at(slab, jn, bs.pos);
+			wi.n_rem += packet_events(&bs, bpk); /* a base packet the neighbour has passed over */
+			wstate_advance(&bs, bpk);
 		}
 	}
 	if (wi.soft_end == (size_t)-1 || wi.soft_end > wi.end) wi.soft_end = wi.end;
@@ -910,7 +970,7 @@ int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step,
 {
 	ctr_rng r = { seed, step, j, 0 };
 	uint16_t* probs = (uint16_t*)malloc(sizeof(uint16_t) * c->L.total * 2);
-	gen_env g = { c, ctr_next, &r, ORC_TOPK_CANON, probs + c->L.total };
+	gen_env g = { c, ctr_next, &r, ORC_TOPK_CANON, probs + c->L.total, 0 };
 	journal jn = { 0 };
 	/* on-walk flags of the base slab */
 	uint8_t* on = (uint8_t*)calloc(c->n, 1);
@@ -940,23 +1000,26 @@ int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step,
 			distinct += !seen;
 		}
 		if (distinct > ORC_MAX_JOURNAL) ok = -1;
+		if (g.repair_picks > ORC_MAX_REPAIR_PICKS) ok = -1; /* the device gives such a neighbour up */
+	}
+	uint32_t wv[4] = { (uint32_t)target, 0xFFFFFFFFu, 0xFFFFFFFFu, 0 };
+	if (ok == 1) {
+		/* the base's rep-free tail: the journal's old values give the base back */
+		size_t from = 0;
+		for (size_t p = 0; p < c->n;) {
+			const orc_packet bp = base_at(slab, &jn, p);
+			if (bp.type == ORC_SHORT_REP || bp.type == ORC_LONG_REP) from = p + 1;
+			p += bp.len;
+		}
+		const window_info wi = window_end(c, slab, &jn, target, from);
+		wv[1] = (uint32_t)wi.end; wv[2] = (uint32_t)wi.soft_end; wv[3] = (uint32_t)wi.dep;
+		/* the device keeps at most ORC_MAX_EVENTS inserted and as many removed events per neighbour (its second
+		 * pass's lists) and visits at most ORC_MAX_WALK of its packets: a neighbour that changes more of the coding than
+		 * that, or whose walk stays apart from the base's for longer, is dropped, like one with too long a journal */
+		if (wi.n_ins > ORC_MAX_EVENTS || wi.n_rem > ORC_MAX_EVENTS || wi.walked > ORC_MAX_WALK) { ok = -1; wv[1] = wv[2] = 0xFFFFFFFFu; wv[3] = 0; }
 	}
 	if (cost) *cost = ok == 1 ? total : ~0ull;
-	if (window) {
-		window[0] = (uint32_t)target;
-		window[1] = window[2] = 0xFFFFFFFFu; window[3] = 0;
-		if (ok == 1) {
-			/* the base's rep-free tail: the journal's old values give the base back */
-			size_t from = 0;
-			for (size_t p = 0; p < c->n;) {
-				const orc_packet bp = base_at(slab, &jn, p);
-				if (bp.type == ORC_SHORT_REP || bp.type == ORC_LONG_REP) from = p + 1;
-				p += bp.len;
-			}
-			const window_info wi = window_end(c, slab, &jn, target, from);
-			window[1] = (uint32_t)wi.end; window[2] = (uint32_t)wi.soft_end; window[3] = (uint32_t)wi.dep;
-		}
-	}
+	if (window) memcpy(window, wv, sizeof wv);
 	/* compact the journal: first old value per position + final value, drop no-ops */
 	size_t nd = 0;
 	if (ok == 1 && ndiffs) {

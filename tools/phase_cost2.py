@@ -9,12 +9,13 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 prepare = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}[cfg]
 data, desc = corpus.config_input(cfg)
-sa = binding.SA(data, neighbours_per_step=K, timing=True, iters_per_epoch=len(data))
+props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
+sa = binding.SA(data, neighbours_per_step=K, timing=True, iters_per_epoch=len(data), **props)
 done = 0
 while prepare != 0 and done < (prepare if prepare > 0 else 6000):
     p = sa.run(prepare if prepare > 0 else 128)
     done += p["steps"]
-    if prepare < 0 and p["bulk_steps"] == 0:
+    if (prepare < 0 and p["bulk_steps"] == 0) or prepare > 0:
         break
 print(f"{cfg}: after {done} steps, {p['packets'] if prepare else '?'} packets")
 sa.set_accept_mode("single")

@@ -256,7 +256,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # set-up: the chain as a long run has it.  By default: until a whole chunk of steps ran without a bulk step
+    # set-up: the chain as a long run has it.  By default: until a whole chunk of steps ran (almost) without a bulk step
     # (the library's AUTO mode has left its bulk phase), every rank for itself
     t_prep = time.perf_counter()
     prep = None
@@ -273,7 +273,8 @@ def main():
             for k in ("steps", "evaluations", "bulk_steps", "accepted"):
                 prep[k] += p[k]
             prep["best_cost"] = p["best_cost"]
-            if args.prepare_steps < 0 and (p["bulk_steps"] == 0 or time.perf_counter() - t_prep > args.prepare_seconds):
+            # over: a chunk with (almost) no bulk step -- around its threshold AUTO still takes the odd block of four
+            if args.prepare_steps < 0 and (p["bulk_steps"] * 16 <= p["steps"] or time.perf_counter() - t_prep > args.prepare_seconds):
                 break
     prepare = prep["steps"] if prep else 0
     t_prep = time.perf_counter() - t_prep

@@ -20,7 +20,7 @@ while prepare != 0 and done < (prepare if prepare > 0 else PREPARE_CAP[cfg]):
     p = sa.run(prepare if prepare > 0 else (64 if len(data) <= (1 << 20) else 128))
     done += p["steps"]
     print("prepare", done, {k: p[k] for k in ("accepted", "bulk_steps", "best_cost", "packets")}, flush=True)
-    if prepare < 0 and p["bulk_steps"] == 0:
+    if prepare < 0 and p["bulk_steps"] * 16 <= p["steps"]:
         break
 st = sa.run(steps)
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})

@@ -102,6 +102,8 @@ typedef struct {
 	uint64_t dropped_neighbours;  /* generates dropped because their journal outgrew 64 slab entries (counted in `failed`;
 	                               * the reference's undo stack grows without bound, packet_slab_undo_stack.c:70-77) */
 	uint64_t improving_neighbours;/* evaluations that cost less than the slab they were made from */
+	uint64_t bulk_rollbacks;      /* bulk steps whose combined parse failed the after-the-fact validation and were taken back
+	                               * as a whole (the safety net of the soft window ends; never seen) */
 } mgl_sa_stats;
 
 /* How a step of K costed neighbours moves the chain (the reference decides after every single

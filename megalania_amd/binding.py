@@ -63,7 +63,8 @@ class Stats(C.Structure):
                 ("packets", C.c_uint64), ("packets_evaluated", C.c_uint64), ("gpu_ms_total", C.c_double),
                 ("gpu_ms_neighbours", C.c_double), ("gpu_ms_rebuild", C.c_double), ("neighbour_launches", C.c_uint64),
                 ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64), ("second_pass_neighbours", C.c_uint64),
-                ("bulk_steps", C.c_uint64), ("dropped_neighbours", C.c_uint64), ("improving_neighbours", C.c_uint64)]
+                ("bulk_steps", C.c_uint64), ("dropped_neighbours", C.c_uint64), ("improving_neighbours", C.c_uint64),
+                ("bulk_rollbacks", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -131,6 +131,7 @@ struct mgl_sa {
 	uint64_t bulk_hold = 0;        /* AUTO: single steps left before bulk steps are tried again (their windows were too long) */
 	BulkBuf bulk;
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
+	uint64_t bulk_rollbacks = 0;   /* bulk steps whose combined parse failed validation and was taken back (never seen) */
 	bool best_unverified = false;  /* packets_best came from another chain: checked when an epoch starts from it */
 };
 
@@ -1007,6 +1008,24 @@ static int launch_bulk_tail(mgl_sa* sa)
 	HIPCHK(hipGetLastError());
 	int rc = launch_pbuild(sa);
 	if (rc) return rc;
+	/* the taken set is checked after the fact (soft window ends rest on an argument about rep distances, not on a
+	 * proof for every coincidence of values): every packet of the new parse against the input; a parse that fails is
+	 * taken back as a whole.  One small read-back per bulk step (a bulk step is a rebuild: milliseconds) */
+	if ((rc = launch_validate(sa))) return rc;
+	{
+		Control now;
+		if ((rc = read_ctl(sa, sa->base, &now))) return rc;
+		if (now.error_flags & MGL_ERR_BAD_PACKET) {
+			hipLaunchKernelGGL(k_bulk_rollback, dim3(64), dim3(256), 0, sa->stream, sa->nbr, sa->bulk, sa->base.v.slab);
+			HIPCHK(hipGetLastError());
+			now.error_flags &= ~MGL_ERR_BAD_PACKET;
+			now.accepted -= now.taken;
+			now.taken = 0;
+			sa->bulk_rollbacks++;
+			if ((rc = write_ctl(sa, sa->base, &now))) return rc;
+			if ((rc = launch_pbuild(sa))) return rc;
+		}
+	}
 	hipLaunchKernelGGL(k_bulk_finish, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, sa->snapshots ? 1 : 0,
 	                   sa->snapshots ? &sa->d_snap_meta[1].valid : (uint32_t*)nullptr);
 	if (sa->snapshots) {
@@ -1035,6 +1054,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	const int mode = (sa->incremental && sa->parallel_build) ? sa->accept_mode : MGL_ACCEPT_SINGLE; /* bulk steps rebuild with the parallel builder */
 	sa->mode_log.clear();
 	uint64_t imp_seen = before.imp_cands, acc_seen = before.accepted, last_block = 0;
+	const uint64_t rollbacks_before = sa->bulk_rollbacks;
 	bool last_bulk = false;
 	HIPCHK(hipEventRecord(sa->ev_begin, sa->stream));
 	for (uint64_t s = 0; s < steps;) {
@@ -1115,6 +1135,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		stats->bulk_steps = after.bulk_steps - before.bulk_steps;
 		stats->dropped_neighbours = after.dropped - before.dropped;
 		stats->improving_neighbours = after.imp_cands - before.imp_cands;
+		stats->bulk_rollbacks = sa->bulk_rollbacks - rollbacks_before;
 	}
 	if (after.error_flags) {
 		char buf[96];

@@ -794,14 +794,14 @@ __device__ __forceinline__ uint32_t packet_events(const DevCtx& c, const mgl_wst
 	mgl_plan_packet(&c.L, &st, mgl_pk_type(pk), mgl_pk_dist(pk), mgl_pk_len(pk), 0u, 0u, 0u, &pl);
 	return pl.nev;
 }
-__device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, const Journal& jn, mgl_wstate st, uint32_t rep_free, uint32_t lane)
+__device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, const Journal& jn, mgl_wstate st, uint32_t lane)
 {
 	mgl_wstate nb = st, bs = st;
 	uint32_t count = 0, wsoft = 0xFFFFFFFFu, taint = 0xFu, dep = 0u, wend = c.n, n_ins = 0, n_rem = 0, walked = 0;
 	bool first = true;
 	for (;;) {
 		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state) {
-			if (wsoft == 0xFFFFFFFFu && nb.pos >= rep_free) wsoft = nb.pos;
+			if (wsoft == 0xFFFFFFFFu) wsoft = nb.pos;
 			if (nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] && nb.dists[3] == bs.dists[3]) { wend = nb.pos; break; }
 			if (nb.ctx_state < 7u && nb.pos < c.n) {
 				/* plain literals up to the base's next non-literal packet: skipped, not visited (the incremental kernel's jump) */
@@ -824,9 +824,9 @@ __device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, 
 			const uint32_t p = nb.pos;
 			const mgl_pk pk = uni64(journal_or_base(jn, slab, p, lane));
 			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk);
-			if (wsoft == 0xFFFFFFFFu) {
-				if (ntype == MGL_SHORT_REP) dep |= taint & 1u;
-				else if (ntype == MGL_LONG_REP) dep |= (taint >> ndist) & 1u;
+			if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) {
+				wsoft = 0xFFFFFFFFu;
+				dep |= ntype == MGL_SHORT_REP ? (taint & 1u) : ((taint >> ndist) & 1u);
 			}
 			if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;
 			else if (ntype == MGL_LONG_REP) taint = (taint & ~((2u << ndist) - 1u)) | ((taint & ((1u << ndist) - 1u)) << 1) | ((taint >> ndist) & 1u);
@@ -1008,7 +1008,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
 		return;
 	}
-	const WinInfo wi = window_end_from_journal(c, b.slab, jn, st_target, ctl->rep_free_from, lane);
+	const WinInfo wi = window_end_from_journal(c, b.slab, jn, st_target, lane);
 	const uint32_t wend = wi.end;
 	if (wi.n_ins > 4096u || wi.n_rem > 4096u || wi.walked > 512u || npicks > 8u) { /* MGL_BIG_CAP / MGL_MAX_WALK / MGL_MAX_REPAIR_PICKS: what the incremental engine's lists hold, its walk visits, its repair picks */
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }

@@ -823,10 +823,9 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	uint32_t count = 0;   /* repair packet counter of packet_slab_neighbour.c:84-86, saturating */
 	uint32_t walked = 0;
 	uint32_t wend = 0; /* where the two walks meet again: the end of this neighbour's window */
-	/* for the bulk step's selection: the first meeting point -- same byte, same ctx_state --
-	 * inside the base's rep-free tail, and whether a rep packet of the neighbour reads a distance from before the window */
+	/* for the bulk step's selection: the first meeting point -- same byte, same ctx_state -- behind
+	 * the last rep packet the walk meets, and whether a rep packet of the neighbour reads a distance from before the window */
 	uint32_t wsoft = 0xFFFFFFFFu, taint = 0xFu, dep = 0u;
-	const uint32_t rep_free = ctl->rep_free_from;
 	bool first_packet = true;
 	uint32_t guard = 0;
 	/* the second pass, too, takes the mutation's pick from the first half when there was one */
@@ -952,7 +951,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					const bool same_ctx = nb.ctx_state == bs.ctx_state;
 					const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] &&
 					                    nb.dists[3] == bs.dists[3];
-					if (same_ctx && wsoft == 0xFFFFFFFFu && nb.pos >= rep_free) wsoft = nb.pos;
+					if (same_ctx && wsoft == 0xFFFFFFFFu) wsoft = nb.pos;
 					if (same_ctx && same_d) break; /* the rest of the file is coded identically */
 					if (same_ctx && nb.ctx_state < 7) {
 						/* plain literals up to the next special packet code identically: skip them */
@@ -1022,9 +1021,9 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					walked++;
 					const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
 					/* which rep distances this packet reads / pushes: bit k of taint = distance k comes from before the window */
-					if (wsoft == 0xFFFFFFFFu) {
-						if (ntype == MGL_SHORT_REP) dep |= taint & 1u;
-						else if (ntype == MGL_LONG_REP) dep |= (taint >> ndist) & 1u;
+					if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) { /* a rep packet: the soft window reaches at least to behind it */
+						wsoft = 0xFFFFFFFFu;
+						dep |= ntype == MGL_SHORT_REP ? (taint & 1u) : ((taint >> ndist) & 1u);
 					}
 					if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;
 					else if (ntype == MGL_LONG_REP) taint = (taint & ~((2u << ndist) - 1u)) | ((taint & ((1u << ndist) - 1u)) << 1) | ((taint >> ndist) & 1u);

@@ -287,6 +287,16 @@ __global__ void __launch_bounds__(256) k_bulk_keep_undo(const Control* ctl, NbrO
 		}
 	}
 }
+/* the safety net of the soft window ends: the combined parse did not validate (k_validate after the rebuild): every
+ * taken journal is taken back */
+__global__ void __launch_bounds__(256) k_bulk_rollback(NbrOut out, BulkBuf bb, mgl_pk* slab)
+{
+	const uint32_t taken = (uint32_t)bb.hdr[1];
+	for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < taken; t += gridDim.x * blockDim.x) {
+		const uint32_t j = bb.taken[t], nd = out.ndiffs[j];
+		for (uint32_t e = 0; e < nd; e++) slab[out.dpos[(size_t)j * MGL_MAX_DIFFS + e]] = out.dold[(size_t)j * MGL_MAX_DIFFS + e];
+	}
+}
 __global__ void k_bulk_reset(BulkBuf bb)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) bb.hdr[1] = 0;

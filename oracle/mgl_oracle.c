@@ -867,11 +867,11 @@ static orc_packet base_at(const orc_packet* slab, const journal* jn, size_t p)
  * they never meet again.  This is where the device's two-pointer walk stops.
  *
  * Two refinements for the bulk step's selection.  soft_end: the first such meeting
- * point -- same byte, same ctx_state, three repair packets done -- that lies in the part of the base parse
- * with no SHORT_REP / LONG_REP packet at or after it (positions >= rep_free_from): the rep distances may
- * still differ there, but nothing from there on reads them, so a second neighbour may start there provided
- * it is self-contained.  dep: the neighbour is NOT self-contained -- some SHORT_REP / LONG_REP packet of its
- * parse inside the window reads a rep distance that was pushed before the window. */
+ * point -- same byte, same ctx_state, three repair packets done -- behind the last SHORT_REP / LONG_REP packet
+ * the walk meets before `end`: the rep distances still differ in [soft_end, end), but no packet there reads
+ * them, so a second neighbour may start there provided it is self-contained.  dep: the neighbour is NOT
+ * self-contained -- some SHORT_REP / LONG_REP packet of its parse reads a rep distance that was pushed before
+ * the window.  (A taken set is checked after the fact: orc_sa_batched validates the combined parse.) */
 typedef struct { size_t end, soft_end; int dep; size_t n_ins, n_rem, walked; } window_info;
 /* events (coded bits with a probability context) of one packet: 1 + 8 for a literal, 4 for a short rep, header +
  * length (+ slot + low distance bits through a reverse tree or the align tree) otherwise; direct bits are not events */
@@ -890,7 +890,7 @@ static size_t packet_events(const wstate* w, orc_packet pk)
 	}
 	return 2 + lenbits + 6 + tail;
 }
-static window_info window_end(const orc_ctx* c, const orc_packet* slab, const journal* jn, size_t target, size_t rep_free_from)
+static window_info window_end(const orc_ctx* c, const orc_packet* slab, const journal* jn, size_t target)
 {
 	window_info wi = { c->n, (size_t)-1, 0, 0, 0, 0 };
 	wstate bs = { 0, 0, { 0, 0, 0, 0 } };
@@ -900,7 +900,7 @@ static window_info window_end(const orc_ctx* c, const orc_packet* slab, const jo
 	int first = 1;
 	for (;;) {
 		if (!first && nb.pos == bs.pos && count >= 3 && nb.ctx_state == bs.ctx_state) {
-			if (wi.soft_end == (size_t)-1 && nb.pos >= rep_free_from) wi.soft_end = nb.pos;
+			if (wi.soft_end == (size_t)-1) wi.soft_end = nb.pos;
 			if (wstate_same(&nb, &bs)) { wi.end = nb.pos; break; }
 			if (nb.ctx_state < 7 && nb.pos < c->n) {
 				/* plain literals up to the base's next non-literal packet are coded identically in both walks: the device
@@ -925,9 +925,10 @@ static window_info window_end(const orc_ctx* c, const orc_packet* slab, const jo
 			wi.walked++;
 			const size_t p = nb.pos;
 			const orc_packet pk = slab[p];
-			if (wi.soft_end == (size_t)-1) { /* inside the (soft) window: what the packet reads */
-				if (pk.type == ORC_SHORT_REP) wi.dep |= taint & 1u;
-				else if (pk.type == ORC_LONG_REP) wi.dep |= (taint >> pk.dist) & 1u;
+			/* a rep packet reads the rep distances: the soft window reaches at least to behind it */
+			if (pk.type == ORC_SHORT_REP || pk.type == ORC_LONG_REP) {
+				wi.soft_end = (size_t)-1;
+				wi.dep |= pk.type == ORC_SHORT_REP ? (taint & 1u) : ((taint >> pk.dist) & 1u);
 			}
 			if (pk.type == ORC_MATCH) taint = (taint << 1) & 0xFu;
 			else if (pk.type == ORC_LONG_REP) {
@@ -1004,14 +1005,7 @@ int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step,
 	}
 	uint32_t wv[4] = { (uint32_t)target, 0xFFFFFFFFu, 0xFFFFFFFFu, 0 };
 	if (ok == 1) {
-		/* the base's rep-free tail: the journal's old values give the base back */
-		size_t from = 0;
-		for (size_t p = 0; p < c->n;) {
-			const orc_packet bp = base_at(slab, &jn, p);
-			if (bp.type == ORC_SHORT_REP || bp.type == ORC_LONG_REP) from = p + 1;
-			p += bp.len;
-		}
-		const window_info wi = window_end(c, slab, &jn, target, from);
+		const window_info wi = window_end(c, slab, &jn, target);
 		wv[1] = (uint32_t)wi.end; wv[2] = (uint32_t)wi.soft_end; wv[3] = (uint32_t)wi.dep;
 		/* the device keeps at most ORC_MAX_EVENTS inserted and as many removed events per neighbour (its second
 		 * pass's lists) and visits at most ORC_MAX_WALK of its packets: a neighbour that changes more of the coding than
@@ -1058,6 +1052,29 @@ static uint64_t ceil_sqrt_u64(uint64_t x)
 	while (r * r > x) r--;
 	while ((r + 1) * (r + 1) <= x) r++;
 	return r * r == x ? r : r + 1;
+}
+
+/* every packet on the walk reproduces the input (the device's k_validate) */
+static int parse_is_valid(const orc_ctx* c, const orc_packet* slab)
+{
+	wstate w = { 0, 0, { 0, 0, 0, 0 } };
+	while (w.pos < c->n) {
+		const orc_packet pk = slab[w.pos];
+		if (pk.type < ORC_LITERAL || pk.type > ORC_LONG_REP || pk.len == 0 || w.pos + pk.len > c->n) return 0;
+		if (pk.type == ORC_LITERAL) { if (pk.len != 1) return 0; }
+		else {
+			uint32_t src;
+			if (pk.type == ORC_SHORT_REP) { if (pk.len != 1) return 0; src = w.dists[0]; }
+			else {
+				if (pk.len < 2 || pk.len > 273 || (pk.type == ORC_LONG_REP && pk.dist > 3)) return 0;
+				src = pk.type == ORC_MATCH ? pk.dist : w.dists[pk.dist];
+			}
+			if (src >= w.pos || src >= c->dict_limit) return 0;
+			for (unsigned i = 0; i < pk.len; i++) if (c->data[w.pos - src - 1 + i] != c->data[w.pos + i]) return 0;
+		}
+		wstate_advance(&w, pk);
+	}
+	return 1;
 }
 
 /* Two neighbours (window = target, end, soft_end, dep) cannot both be taken: with A the one that starts first,
@@ -1150,6 +1167,15 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 		for (uint32_t j = 0; j < K; j++) {
 			if (!take[j]) continue;
 			for (size_t e = 0; e < nd[j]; e++) slab[diffs[(size_t)j * ORC_MAX_JOURNAL + e].position] = diffs[(size_t)j * ORC_MAX_JOURNAL + e].new_packet;
+		}
+		if (ntaken && bulk && !parse_is_valid(c, slab)) {
+			/* the safety net of the soft window ends: a combination that is not a valid parse is taken back as a whole
+			 * (never seen to happen; the device checks the same thing with k_validate after its rebuild) */
+			for (uint32_t j = 0; j < K; j++) {
+				if (!take[j]) continue;
+				for (size_t e = 0; e < nd[j]; e++) slab[diffs[(size_t)j * ORC_MAX_JOURNAL + e].position] = diffs[(size_t)j * ORC_MAX_JOURNAL + e].old_packet;
+			}
+			ntaken = 0;
 		}
 		if (ntaken) {
 			cur = (!bulk) ? costs[minj] : orc_cost_slab(c, slab, NULL, NULL, NULL, NULL, NULL);

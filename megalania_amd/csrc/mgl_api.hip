@@ -410,7 +410,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	free_base(sa->base); free_base(sa->scratch);
 	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.win); dfree(sa->nbr.win2); dfree(sa->nbr.dpos);
-	dfree(sa->bulk.ckey); dfree(sa->bulk.cwin); dfree(sa->bulk.taken); dfree(sa->bulk.hdr);
+	dfree(sa->bulk.ckey); dfree(sa->bulk.cwin); dfree(sa->bulk.taken); dfree(sa->bulk.cstate); dfree(sa->bulk.hdr);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	free_b2(sa->b2, false);
@@ -577,6 +577,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMalloc(&sa->bulk.ckey, sizeof(uint64_t) * K));
 	HIPCHK(hipMalloc(&sa->bulk.cwin, sizeof(uint4) * K));
 	HIPCHK(hipMalloc(&sa->bulk.taken, sizeof(uint32_t) * K));
+	HIPCHK(hipMalloc(&sa->bulk.cstate, 2u * (size_t)K));
 	HIPCHK(hipMalloc(&sa->bulk.hdr, sizeof(unsigned long long) * 8));
 	{
 		const unsigned long long h0[8] = { 0, 0, 0, 0, 0, 0, ~0ull, 0 };
@@ -1003,7 +1004,8 @@ static int launch_bulk_tail(mgl_sa* sa)
 	const DecideArgs a = decide_args(sa);
 	const uint32_t blocks = (K + 255u) / 256u;
 	hipLaunchKernelGGL(k_bulk_prep, dim3(blocks), dim3(256), 0, sa->stream, sa->ctx, sa->base.ctl, sa->nbr, a, sa->bulk);
-	hipLaunchKernelGGL(k_bulk_select, dim3(blocks), dim3(256), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, sa->base.v.slab);
+	for (uint32_t r = 0; r < MGL_BULK_ROUNDS; r++)
+		hipLaunchKernelGGL(k_bulk_round, dim3(blocks), dim3(256), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, sa->base.v.slab, K, r);
 	hipLaunchKernelGGL(k_bulk_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, a);
 	HIPCHK(hipGetLastError());
 	int rc = launch_pbuild(sa);

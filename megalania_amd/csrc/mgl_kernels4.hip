@@ -10,7 +10,7 @@
  *
  *   k_decide        single mode: the acceptable neighbour with the smallest key wins; the accept
  *                   path (mgl_kernels3.hip) folds it into the base structures incrementally.
- *   k_bulk_prep / k_bulk_select / k_bulk_end / k_bulk_finish / k_bulk_keep_*
+ *   k_bulk_prep / k_bulk_round / k_bulk_end / k_bulk_finish / k_bulk_keep_*
  *                   bulk mode: every acceptable neighbour whose window [target, end) overlaps no
  *                   acceptable neighbour of smaller key is taken in the same step.  Windows are
  *                   where a neighbour's walk differs from the base's, so disjoint windows give a
@@ -134,6 +134,7 @@ struct BulkBuf {
 	uint64_t* ckey;     /* K: keys of the acceptable neighbours (compacted, any order) */
 	uint4* cwin;        /* K: their windows: target, end, soft end, dep */
 	uint32_t* taken;    /* K: neighbour indices taken this step */
+	uint8_t* cstate;    /* 2 x K: selection state per candidate (0 undecided, 1 taken, 2 rejected), one array per round parity */
 	unsigned long long* hdr; /* [0] acceptable [1] taken [2] valid [3] walked [4] improving [5] dropped [6] smallest taken key */
 };
 
@@ -186,29 +187,47 @@ __device__ __forceinline__ bool windows_conflict(const uint4& x, const uint4& y)
 	if (a.x == b.x) return true;
 	return !(a.z <= b.x && (b.w == 0u || a.y <= b.x));
 }
-/* a candidate is taken iff no candidate of smaller key conflicts with it; the taken ones write their
- * journals into the slab (their windows are pairwise disjoint, so no two of them touch one entry) */
-__global__ void __launch_bounds__(256) k_bulk_select(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab)
+/* Selection = the greedy independent set in key order (a candidate is taken iff no TAKEN candidate of smaller key
+ * conflicts with it), computed in MGL_BULK_ROUNDS synchronous rounds: in a round an undecided candidate is rejected
+ * if a taken smaller-key candidate conflicts with it, taken if every conflicting smaller-key candidate is already
+ * rejected, and stays undecided otherwise; states are read from the previous round's array and written to the next
+ * (so the result does not depend on scheduling), and what is still undecided after the last round is rejected.
+ * The taken ones write their journals into the slab at once (taken windows are pairwise compatible, so no two of
+ * them touch one entry). */
+__global__ void __launch_bounds__(256) k_bulk_round(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab, uint32_t K, uint32_t round)
 {
 	__shared__ uint64_t s_key[256];
 	__shared__ uint4 s_win[256];
+	__shared__ uint8_t s_st[256];
 	const uint32_t n = (uint32_t)bb.hdr[0];
 	if (blockIdx.x * blockDim.x >= n) return;
+	const uint8_t* st_in = bb.cstate + (size_t)(round & 1u) * K;
+	uint8_t* st_out = bb.cstate + (size_t)((round + 1u) & 1u) * K;
 	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool mine = a < n;
+	const uint8_t my = (mine && round) ? st_in[a] : (uint8_t)0;
+	if (!__syncthreads_or(mine && my == 0)) { if (mine) st_out[a] = my; return; }
 	const uint64_t key = mine ? bb.ckey[a] : 0ull;
 	const uint4 w = mine ? bb.cwin[a] : make_uint4(0u, 0u, 0u, 0u);
-	bool lose = false;
+	bool lose = false, blocked = false;
 	for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
 		__syncthreads();
-		if (t0 + threadIdx.x < n) { s_key[threadIdx.x] = bb.ckey[t0 + threadIdx.x]; s_win[threadIdx.x] = bb.cwin[t0 + threadIdx.x]; }
+		if (t0 + threadIdx.x < n) {
+			s_key[threadIdx.x] = bb.ckey[t0 + threadIdx.x]; s_win[threadIdx.x] = bb.cwin[t0 + threadIdx.x];
+			s_st[threadIdx.x] = round ? st_in[t0 + threadIdx.x] : (uint8_t)0;
+		}
 		__syncthreads();
 		const uint32_t cnt = (n - t0) < 256u ? (n - t0) : 256u;
-		if (mine && !lose)
+		if (mine && my == 0 && !lose)
 			for (uint32_t i = 0; i < cnt; i++)
-				lose = lose || (s_key[i] < key && windows_conflict(s_win[i], w));
+				if (s_st[i] != 2 && s_key[i] < key && windows_conflict(s_win[i], w)) {
+					if (s_st[i] == 1) lose = true; else blocked = true;
+				}
 	}
-	if (!mine || lose) return;
+	if (!mine) return;
+	const uint8_t now = my ? my : (lose ? (uint8_t)2 : (blocked ? (uint8_t)0 : (uint8_t)1));
+	st_out[a] = now;
+	if (my != 0 || now != 1) return;
 	const uint32_t j = (uint32_t)(key & 0xFFFFFu);
 	const unsigned long long at = atomicAdd(&bb.hdr[1], 1ull);
 	bb.taken[at] = j;

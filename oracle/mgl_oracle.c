@@ -807,6 +807,7 @@ int orc_sa_iters(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_i
 /* ---------------------------------------------------------------- batched semantics */
 #define ORC_MAX_JOURNAL 64
 #define ORC_MAX_EVENTS 4096
+#define ORC_BULK_ROUNDS 8u
 #define ORC_MAX_REPAIR_PICKS 8 /* top-K picks the repair of one neighbour may need (invalid LONG_REPs, packet_slab_neighbour.c:99-109) */
 #define ORC_MAX_WALK 512 /* neighbour packets the device's two-pointer walk visits before it gives a neighbour up */
 static uint64_t mix64(uint64_t z)
@@ -1156,13 +1157,34 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 		if (!bulk) {
 			if (minj != ~0u) { take[minj] = 1; ntaken = 1; }
 		} else {
-			for (uint32_t j = 0; j < K; j++) {
-				if (keys[j] == ~0ull) continue;
-				int lose = 0;
-				for (uint32_t i = 0; i < K && !lose; i++)
-					lose = keys[i] < keys[j] && windows_conflict(win + 4 * (size_t)i, win + 4 * (size_t)j);
-				if (!lose) { take[j] = 1; ntaken++; }
+			/* the greedy independent set in key order, in ORC_BULK_ROUNDS synchronous rounds (states read from the
+			 * previous round, written for the next; still undecided at the end = rejected) -- the device's
+			 * k_bulk_round, round for round */
+			uint8_t* st = (uint8_t*)calloc(2 * (size_t)K, 1);
+			uint32_t* acc = (uint32_t*)malloc(sizeof(uint32_t) * K);
+			uint32_t nacc = 0;
+			for (uint32_t j = 0; j < K; j++) if (keys[j] != ~0ull) acc[nacc++] = j;
+			for (uint32_t r = 0; r < ORC_BULK_ROUNDS; r++) {
+				const uint8_t* in = st + (size_t)(r & 1u) * K;
+				uint8_t* outp = st + (size_t)((r + 1u) & 1u) * K;
+				for (uint32_t aj = 0; aj < nacc; aj++) {
+					const uint32_t j = acc[aj];
+					outp[j] = in[j];
+					if (in[j]) continue;
+					int lose = 0, blocked = 0;
+					for (uint32_t ai = 0; ai < nacc && !lose; ai++) {
+						const uint32_t i = acc[ai];
+						if (in[i] == 2 || !(keys[i] < keys[j]) || !windows_conflict(win + 4 * (size_t)i, win + 4 * (size_t)j)) continue;
+						if (in[i] == 1) lose = 1; else blocked = 1;
+					}
+					outp[j] = lose ? 2 : (blocked ? 0 : 1);
+				}
 			}
+			free(acc);
+			const uint8_t* fin = st + (size_t)(ORC_BULK_ROUNDS & 1u) * K;
+			for (uint32_t j = 0; j < K; j++)
+				if (keys[j] != ~0ull && fin[j] == 1) { take[j] = 1; ntaken++; }
+			free(st);
 		}
 		for (uint32_t j = 0; j < K; j++) {
 			if (!take[j]) continue;

@@ -89,7 +89,8 @@ def hip_lib():
         if not os.path.exists(HIP_SO):
             raise MglError(f"{HIP_SO} is missing: run `python -m megalania_amd.build` (hipcc, gfx950). "
                            "There is no CPU implementation of the search path.")
-        L = C.CDLL(HIP_SO)
+        # MGL_HIP_SO: another build of the same library (tools/ab_builds.sh compares two builds on one state)
+        L = C.CDLL(os.environ.get("MGL_HIP_SO") or HIP_SO)
         L.mgl_version.restype = C.c_char_p
         L.mgl_last_error.restype = C.c_char_p
         L.mgl_device_count.restype = C.c_int

@@ -331,7 +331,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			                   4096u + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_pick, sa->d_todo, sa->d_counts,
 			                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
-			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), 4096u + sa->per_wave_rest, st, sa->ctx,
+			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), sa->per_wave_rest, st, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
 			                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
 			HIPCHK(hipEventRecord(sa->ev_rest[h], st));

@@ -574,9 +574,18 @@ __device__ __forceinline__ uint32_t literal_run_events(const DevCtx& c, Changes&
 __device__ void model_load(const DevCtx& c, const Base2& b, uint16_t* probs, const uint16_t* T, uint32_t y, uint32_t lane)
 {
 	const uint32_t ck = y >> MGL_CK2_SHIFT;
-	const uint32_t* src = (const uint32_t*)(b.ck_probs + (size_t)ck * b.ck_elems);
-	uint32_t* dst = (uint32_t*)probs;
-	for (uint32_t i = lane; i < b.ck_elems / 2; i += 64) dst[i] = src[i];
+	/* 16 bytes per lane and four loads in flight per trip (rows are 16-byte multiples, 16-byte aligned on both sides):
+	 * a 5 KiB model is two round trips instead of twenty-one */
+	const uint4* src = (const uint4*)(b.ck_probs + (size_t)ck * b.ck_elems);
+	uint4* dst = (uint4*)probs;
+	const uint32_t n16 = b.ck_elems / 8u;
+	for (uint32_t base = 0; base < n16; base += 256u) {
+		uint4 r[4];
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) { const uint32_t i = base + u * 64u + lane; if (i < n16) r[u] = src[i]; }
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) { const uint32_t i = base + u * 64u + lane; if (i < n16) dst[i] = r[u]; }
+	}
 	/* first base packet start in [ck << shift, y): one bitmap word holds the whole checkpoint block */
 	const uint32_t first = ck << MGL_CK2_SHIFT;
 	const uint64_t bits = b.onwalk[first >> 6] & ((y & 63u) ? ((1ull << (y & 63u)) - 1ull) : 0ull) & (~0ull << (first & 63u));
@@ -694,7 +703,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	 * lists only start to fill once the mutated packet is known.  A repair that needs another
 	 * top-K pick while the lists are live is handed to the BIG pass, whose lists are in global
 	 * memory.  This keeps 11 instead of 8 wavefronts per CU. */
-	unsigned char* mine = smem + 4096 + (size_t)wid * per_wave_bytes;
+	unsigned char* mine = smem + (MODE == MGL_NBR_REST ? 0u : 4096u) + (size_t)wid * per_wave_bytes;
 	Journal jn;
 	jn.old = (mgl_pk*)mine;
 	jn.neu = jn.old + MGL_MAX_DIFFS;
@@ -865,6 +874,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 				spilled = true;
 			}
 			model_load(c, b, probs, T, pick_pos, lane);
+			if (!pick_is_mutation) prof_mark(prof, 5, lane); /* repair: base model at the pick position */
 			if (pick_is_mutation) {
 				prof_mark(prof, 1, lane); /* model at target */
 				if (c.diag_stop == 2) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = probs[lane]; } return; }
@@ -916,7 +926,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			}
 			wave_sync();
 			if (too_many) { phase = P_OUT; continue; }
-			if (sim_overlay) phase = P_TOPK;
+			if (sim_overlay) { prof_mark(prof, 6, lane); phase = P_TOPK; } /* repair: model overridden by the re-simulated values */
 			else { delta = r; prof_mark(prof, 4, lane); phase = P_OUT; }
 		}
 		if (MODE != MGL_NBR_REST && phase == P_TOPK) {
@@ -938,6 +948,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			} else {
 				picked_pk = ok ? picked : pick_inc;
 				have_pick = true;
+				prof_mark(prof, 7, lane); /* repair: top-K */
 			}
 			win.base = 0xFFFFFFFFu;
 			phase = P_WALK;
@@ -1067,7 +1078,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 				}
 			}
 			if (walk_long) { phase = P_OUT; continue; }
-			if (request_pick) { phase = P_MODEL; continue; }
+			if (request_pick) { prof_mark(prof, 3, lane); phase = P_MODEL; continue; }
 			prof_mark(prof, 3, lane); /* window walk */
 			if (c.diag_stop == 4) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = ch.n_ins + ch.n_rem; } return; }
 			if (ch.overflow || jn.overflow || too_many) { phase = P_OUT; continue; }
@@ -1133,9 +1144,12 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	if (BIG && blockIdx.x * waves >= *big.todo_in_count) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
-	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block) */
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
-	__syncthreads();
+	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block); the second
+	 * half of the split form prices nothing (its re-simulation is k_sim's) and has no table: 4 KiB less per workgroup */
+	if (MODE != MGL_NBR_REST) {
+		for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
+		__syncthreads();
+	}
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	if (BIG) {
 		const uint32_t n = *big.todo_in_count;

@@ -21,9 +21,9 @@ print(f"{cfg}: after {done} steps, {p['packets'] if prepare else '?'} packets")
 sa.set_accept_mode("single")
 names = {1: "target + state_at", 2: "+ model_at (checkpoint + replay)", 31: "  top-K: price tables", 32: "  top-K: + literal/short-rep", 33: "  top-K: + bucket bounds",
          34: "  top-K: + runs of the deeper orders", 35: "  top-K: + rep pass", 36: "  top-K: + 16-byte run", 37: "  top-K: + 8-byte run", 38: "  top-K: + 4-byte run", 39: "  top-K: all sources, short ones filter only",
-         3: "+ top-K complete / mutate", 4: "+ window walk", 0: "+ chain_sim (everything)"}
+         3: "+ top-K complete / mutate", 4: "+ window walk", 41: "  re-simulation: distinct contexts listed", 42: "  re-simulation: + chain search, first chunk", 43: "  re-simulation: + merge part", 0: "+ chain_sim (everything)"}
 prev = 0.0
-for stop in (1, 2, 31, 32, 33, 34, 35, 36, 37, 39, 38, 3, 4, 0):
+for stop in (1, 2, 31, 32, 33, 34, 35, 36, 37, 39, 38, 3, 4, 41, 42, 43, 0):
     sa.L.mgl_debug_set(sa.h, 0, stop)
     sa.run(2)
     st = sa.run(10)

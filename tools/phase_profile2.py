@@ -18,8 +18,8 @@ base = sa.debug_dump(9, np.uint64).copy()
 st = sa.run(16)
 p = sa.debug_dump(9, np.uint64)
 d = p[:32].astype(np.int64) - base[:32].astype(np.int64)
-names = ["state_at", "model_at", "top-K", "window walk", "chain_sim"]
-tot = float(d[:5].sum())
+names = ["state_at", "model_at", "top-K", "window walk", "chain_sim", "repair: model", "repair: overlay sim", "repair: top-K"]
+tot = float(d[:8].sum())
 print(f"{cfg} after {done} steps ({'second pass' if os.environ.get('MGL_PROF_BIG') else 'regular launch'}): nbr {st['gpu_ms_neighbours']/16:.3f} ms/step, second-pass neighbours/step {st['second_pass_neighbours']/16:.1f}")
 for i, nm in enumerate(names):
     cnt = int(d[8 + i])

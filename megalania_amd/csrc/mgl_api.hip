@@ -35,6 +35,11 @@ static int fail(int code, const std::string& msg)
 			return fail(MGL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
 	} while (0)
 
+/* Look-ahead (opt-in, MGL_LOOKAHEAD=1) keeps five streams busy -- the step's own chain, the second slice, the re-simulations,
+ * two speculative slices -- and streams that share a hardware queue run one behind the other: more queues than the runtime's
+ * default of four, set before the runtime initialises (its first call) and only if the user has not set the variable. */
+__attribute__((constructor)) static void mgl_more_hw_queues(void) { if (getenv("MGL_LOOKAHEAD")) setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" const char* mgl_version(void) { return "megalania-hip 0.1 (gfx950)"; }
 extern "C" const char* mgl_last_error(void) { return g_err.c_str(); }
 extern "C" int mgl_device_count(void)
@@ -133,6 +138,15 @@ struct mgl_sa {
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
 	uint64_t bulk_rollbacks = 0;   /* bulk steps whose combined parse failed validation and was taken back (never seen) */
 	bool best_unverified = false;  /* packets_best came from another chain: checked when an epoch starts from it */
+	/* look-ahead (k_la_check): the next step's pick + window walk run beside this step's tail into the other buffer set */
+	struct NbrSet { NbrOut nbr; uint4* pickrec; uint4* pickstate; uint4* sim_hdr; uint16_t* sim_keys; uint32_t* sim_pos; uint32_t* todo; uint32_t* counts; };
+	NbrSet alt = {};
+	bool la_enabled = false, la_ready = false;
+	uint8_t* d_la_mark = nullptr;
+	uint32_t* d_la_list = nullptr;
+	uint32_t* d_la_hdr = nullptr;  /* [0] neighbours to evaluate again, [1] second-pass entries of the speculative launch */
+	hipStream_t stream5 = nullptr, stream6 = nullptr;
+	hipEvent_t ev_la_check = nullptr, ev_la_zero = nullptr, ev_redo = nullptr, ev_spec[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
 static uint64_t ceil_sqrt_u64(uint64_t x)
@@ -302,7 +316,62 @@ static int launch_apply(mgl_sa* sa)
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
-static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_counts = true)
+static mgl_sa::NbrSet cur_set(const mgl_sa* sa)
+{
+	mgl_sa::NbrSet t = { sa->nbr, sa->d_pickrec, sa->d_pickstate, sa->big.sim_hdr, sa->big.sim_keys, sa->big.sim_pos, sa->d_todo, sa->d_counts };
+	return t;
+}
+static void use_set(mgl_sa* sa, const mgl_sa::NbrSet& t)
+{
+	sa->nbr = t.nbr; sa->d_pickrec = t.pickrec; sa->d_pickstate = t.pickstate;
+	sa->big.sim_hdr = t.sim_hdr; sa->big.sim_keys = t.sim_keys; sa->big.sim_pos = t.sim_pos;
+	sa->d_todo = t.todo; sa->d_counts = t.counts;
+	sa->big.todo_in = t.todo; sa->big.todo_in_count = t.counts; sa->big.spill_ctr = t.counts + 2;
+}
+static uint32_t nbr_slices(const mgl_sa* sa)
+{
+	const uint32_t K = sa->cfg.neighbours_per_step;
+	return (sa->halves >= 2 && K >= 1024) ? sa->halves : 1u;
+}
+/* the first two thirds of the split form -- pick, then window walk -- of every slice of a step into the buffer set `t`;
+ * slices alternate between the two streams, done[h] is recorded behind slice h's walk */
+static int launch_pick_rest(mgl_sa* sa, const mgl_sa::NbrSet& t, uint64_t step_override, hipStream_t s_even, hipStream_t s_odd, hipEvent_t* done)
+{
+	const uint32_t K = sa->cfg.neighbours_per_step, slices = nbr_slices(sa);
+	BigScratch g = sa->big;
+	g.sim_hdr = t.sim_hdr; g.sim_keys = t.sim_keys; g.sim_pos = t.sim_pos;
+	g.todo_in = t.todo; g.todo_in_count = t.counts; g.spill_ctr = t.counts + 2;
+	for (uint32_t h = 0; h < slices; h++) {
+		const uint32_t j0 = (uint32_t)((uint64_t)K * h / slices), j1 = (uint32_t)((uint64_t)K * (h + 1) / slices);
+		hipStream_t st = (h & 1u) ? s_odd : s_even;
+		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_PICK>), dim3((j1 - j0 + sa->pick_waves - 1) / sa->pick_waves), dim3(64 * sa->pick_waves),
+		                   4096u + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, t.nbr, sa->per_wave_pick, t.todo, t.counts,
+		                   (unsigned long long*)nullptr, g, t.pickrec, j0, j1, t.pickstate);
+		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), sa->per_wave_rest, st, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, t.nbr, sa->per_wave_rest, t.todo, t.counts,
+		                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, g, t.pickrec, j0, j1, t.pickstate);
+		HIPCHK(hipEventRecord(done[h], st));
+	}
+	HIPCHK(hipGetLastError());
+	return MGL_OK;
+}
+/* look-ahead: the NEXT step's pick + window walk, speculatively, into the other buffer set; they start once this step's own
+ * walks are through (after_check: once k_la_check has run) and the accept waits for them (launch_apply's caller) */
+static int launch_lookahead(mgl_sa* sa, uint64_t gstep_next, bool after_check)
+{
+	const uint32_t slices = nbr_slices(sa);
+	if (after_check) HIPCHK(hipStreamWaitEvent(sa->stream5, sa->ev_la_check, 0));
+	else for (uint32_t h = 0; h < slices; h++) HIPCHK(hipStreamWaitEvent(sa->stream5, sa->ev_rest[h], 0));
+	HIPCHK(hipMemsetAsync(sa->alt.counts, 0, 8 * sizeof(uint32_t), sa->stream5));
+	HIPCHK(hipEventRecord(sa->ev_la_zero, sa->stream5));
+	HIPCHK(hipStreamWaitEvent(sa->stream6, sa->ev_la_zero, 0));
+	int rc = launch_pick_rest(sa, sa->alt, gstep_next, sa->stream5, sa->stream6, sa->ev_spec);
+	if (rc) return rc;
+	sa->la_ready = true;
+	return MGL_OK;
+}
+static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_counts = true, bool from_lookahead = false)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
 	if (!sa->incremental) {
@@ -316,33 +385,49 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 8 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	const bool split_now = sa->split_nbr && !sa->form_single;
+	const uint32_t sim_lds_regular = ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u;
 	if (split_now) {
 		/* the step's neighbours in slices on two streams: while the slowest wavefronts of one slice's kernel finish,
 		 * the other slice's kernels keep the CUs busy.  The re-simulation kernels run on a third stream: the second
 		 * pass below needs the walks, not the re-simulations, and its few long-running wavefronts overlap with them. */
-		const uint32_t slices = (sa->halves >= 2 && K >= 1024) ? sa->halves : 1u;
-		HIPCHK(hipEventRecord(sa->ev_fork, sa->stream));
-		if (slices >= 2) HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_fork, 0));
-		HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_fork, 0));
+		const uint32_t slices = nbr_slices(sa);
+		if (!from_lookahead) {
+			HIPCHK(hipEventRecord(sa->ev_fork, sa->stream));
+			if (slices >= 2) HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_fork, 0));
+			HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_fork, 0));
+			int rc = launch_pick_rest(sa, cur_set(sa), step_override, sa->stream, sa->stream2, sa->ev_rest);
+			if (rc) return rc;
+		} else {
+			/* pick + walk of this step ran ahead, beside the previous step's tail (launch_lookahead): keep what the accepted
+			 * move cannot have touched, evaluate the others again in the one-kernel form (a list, usually short) */
+			HIPCHK(hipMemsetAsync(sa->d_la_hdr, 0, 2 * sizeof(uint32_t), sa->stream));
+			hipLaunchKernelGGL(k_la_check, dim3((K + 255u) / 256u), dim3(256), 0, sa->stream, sa->ctx, sa->b2, (const Control*)sa->base.ctl, sa->nbr,
+			                   (const uint4*)sa->d_pickstate, sa->big.sim_hdr, (const uint32_t*)sa->d_counts, sa->d_la_mark, sa->d_la_list, sa->d_la_hdr, sa->cfg.seed, K);
+			HIPCHK(hipEventRecord(sa->ev_la_check, sa->stream));
+			HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_la_check, 0));
+			HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_la_check, 0));
+		}
 		for (uint32_t h = 0; h < slices; h++) {
 			const uint32_t j0 = (uint32_t)((uint64_t)K * h / slices), j1 = (uint32_t)((uint64_t)K * (h + 1) / slices);
-			hipStream_t st = (h & 1u) ? sa->stream2 : sa->stream; /* slices alternate between the two streams */
-			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_PICK>), dim3((j1 - j0 + sa->pick_waves - 1) / sa->pick_waves), dim3(64 * sa->pick_waves),
-			                   4096u + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
-			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_pick, sa->d_todo, sa->d_counts,
-			                   (unsigned long long*)nullptr, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
-			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), sa->per_wave_rest, st, sa->ctx,
-			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_rest, sa->d_todo, sa->d_counts,
-			                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, sa->big, sa->d_pickrec, j0, j1, sa->d_pickstate);
-			HIPCHK(hipEventRecord(sa->ev_rest[h], st));
 			/* the second half's re-simulation, several wavefronts per neighbour; a neighbour with more touched contexts
 			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
-			HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
-			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
+			if (!from_lookahead) HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
+			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
 			                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 		}
 		HIPCHK(hipEventRecord(sa->ev_sim, sa->stream3));
-		for (uint32_t h = 1; h < slices; h += 2) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_rest[h], 0)); /* the walks of the other stream's slices */
+		if (!from_lookahead) {
+			for (uint32_t h = 1; h < slices; h += 2) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_rest[h], 0)); /* the walks of the other stream's slices */
+		} else {
+			BigScratch g = sa->big;
+			g.la_list = sa->d_la_list; g.la_count = sa->d_la_hdr;
+			const uint32_t grid = blocks2 < 4096u ? blocks2 : 4096u; /* strides over the list */
+			/* on the second stream, beside the second pass over the speculative launch's entries; its own entries get a second pass of their own below */
+			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(grid), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream2, sa->ctx,
+			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
+			                   sa->d_prof, g, sa->d_pickrec, 0u, K, sa->d_pickstate);
+			HIPCHK(hipEventRecord(sa->ev_redo, sa->stream2));
+		}
 	}
 	if (!sa->split_nbr || sa->form_single) { /* the one-kernel form */
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
@@ -357,13 +442,29 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	big_now.lds_cache = 1u;
 	const uint32_t big_lds = sa->nbr2_lds + 12u * MGL_BIG_CAP; /* + a copy of both lists for the re-simulations */
 	if (!split_now || getenv("MGL_BIG_INLINE_SIM")) big_now.sim_hdr2 = nullptr; /* the one-kernel form has no k_sim launch to hand over to */
+	const bool la_step = from_lookahead && split_now;
+	if (la_step) {
+		/* first the entries the speculative launch made (their count is fixed since k_la_check; the ones evaluated again are passed by) ... */
+		big_now.la_mark = sa->d_la_mark; big_now.la_spec_count = sa->d_la_hdr + 1;
+		big_now.todo_in_count = sa->d_la_hdr + 1;
+	}
 	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
 	                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
+	if (la_step) {
+		/* ... then, once the fresh evaluations are through, the entries they added */
+		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_redo, 0));
+		big_now.todo_in_count = sa->d_counts;
+		big_now.todo_first = sa->d_la_hdr + 1;
+		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 256u ? bigblocks : 256u), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
+		                   (unsigned long long*)nullptr, big_now, sa->d_pickrec, 0u, K, sa->d_pickstate);
+		big_now.todo_first = nullptr;
+	}
 	if (split_now) {
 		/* the second pass handed its final re-simulations to k_sim as well (headers in sim_hdr2): a small grid over its list */
 		const uint32_t sim_lds = ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + MGL_SIM2_CAP * 16u;
-		hipLaunchKernelGGL(k_sim, dim3(256), dim3(64 * MGL_SIM_WAVES), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, sa->big, 0u, K,
+		hipLaunchKernelGGL(k_sim, dim3(256), dim3(64 * MGL_SIM_WAVES), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, big_now, 0u, K,
 		                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts);
 		/* what k_sim (either launch) could not take: a late second pass that re-simulates inline */
 		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
@@ -417,6 +518,18 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
 	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
 	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.rep_free); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
+	{
+		mgl_sa::NbrSet& t = sa->alt;
+		dfree(t.nbr.cost); dfree(t.nbr.ndiffs); dfree(t.nbr.walked); dfree(t.nbr.win); dfree(t.nbr.win2); dfree(t.nbr.dpos); dfree(t.nbr.dold); dfree(t.nbr.dnew);
+		dfree(t.pickrec); dfree(t.pickstate); dfree(t.sim_hdr); dfree(t.sim_keys); dfree(t.sim_pos); dfree(t.todo); dfree(t.counts);
+		dfree(sa->d_la_mark); dfree(sa->d_la_list); dfree(sa->d_la_hdr);
+		if (sa->stream5) (void)hipStreamDestroy(sa->stream5);
+		if (sa->stream6) (void)hipStreamDestroy(sa->stream6);
+		if (sa->ev_la_check) (void)hipEventDestroy(sa->ev_la_check);
+		if (sa->ev_la_zero) (void)hipEventDestroy(sa->ev_la_zero);
+		if (sa->ev_redo) (void)hipEventDestroy(sa->ev_redo);
+		for (int i = 0; i < 8; i++) if (sa->ev_spec[i]) (void)hipEventDestroy(sa->ev_spec[i]);
+	}
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
@@ -750,6 +863,47 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&g.sim_hdr2, sizeof(uint4) * (size_t)K));
 			HIPCHK(hipMalloc(&g.sim_slot2, sizeof(uint32_t) * (size_t)K));
 			HIPCHK(hipMemset(g.sim_hdr2, 0xFF, sizeof(uint4) * (size_t)K));
+			/* look-ahead: a second set of everything pick + walk write, the check's list and marks, two more streams */
+			/* Opt-in (MGL_LOOKAHEAD=1): exact (tests/test_gpu_parity.py runs it against the plain order), but slower on MI355X as
+			 * measured (c3: 1.58 ms per step against 1.37, profiles/r02_lookahead_c3.txt): the pick kernel is bound by LDS capacity
+			 * and the re-simulations by the memory system, so kernels running beside each other take their time from each other. */
+			sa->la_enabled = sa->incremental_apply && getenv("MGL_LOOKAHEAD") != nullptr;
+			if (sa->la_enabled) {
+				mgl_sa::NbrSet& t = sa->alt;
+				HIPCHK(hipMalloc(&t.nbr.cost, sizeof(uint64_t) * K));
+				HIPCHK(hipMalloc(&t.nbr.ndiffs, sizeof(uint32_t) * K));
+				HIPCHK(hipMalloc(&t.nbr.walked, sizeof(uint32_t) * K));
+				HIPCHK(hipMalloc(&t.nbr.win, sizeof(uint32_t) * 2 * K));
+				HIPCHK(hipMemset(t.nbr.win, 0xFF, sizeof(uint32_t) * 2 * K));
+				HIPCHK(hipMalloc(&t.nbr.win2, sizeof(uint32_t) * K));
+				HIPCHK(hipMemset(t.nbr.win2, 0xFF, sizeof(uint32_t) * K));
+				HIPCHK(hipMalloc(&t.nbr.dpos, sizeof(uint32_t) * K * MGL_MAX_DIFFS));
+				HIPCHK(hipMalloc(&t.nbr.dold, sizeof(mgl_pk) * K * MGL_MAX_DIFFS));
+				HIPCHK(hipMalloc(&t.nbr.dnew, sizeof(mgl_pk) * K * MGL_MAX_DIFFS));
+				HIPCHK(hipMalloc(&t.pickrec, sizeof(uint4) * K));
+				HIPCHK(hipMalloc(&t.pickstate, sizeof(uint4) * 2 * K));
+				HIPCHK(hipMalloc(&t.sim_hdr, sizeof(uint4) * (size_t)K));
+				HIPCHK(hipMemset(t.sim_hdr, 0xFF, sizeof(uint4) * (size_t)K));
+				HIPCHK(hipMalloc(&t.sim_keys, sizeof(uint16_t) * 2u * sa->chg_cap * (size_t)K));
+				HIPCHK(hipMalloc(&t.sim_pos, sizeof(uint32_t) * 2u * sa->chg_cap * (size_t)K));
+				HIPCHK(hipMalloc(&t.todo, sizeof(uint32_t) * (K + 1)));
+				HIPCHK(hipMemset(t.todo, 0, sizeof(uint32_t) * (K + 1)));
+				HIPCHK(hipMalloc(&t.counts, sizeof(uint32_t) * 16));
+				HIPCHK(hipMemset(t.counts, 0, sizeof(uint32_t) * 16));
+				HIPCHK(hipMalloc(&sa->d_la_mark, K));
+				HIPCHK(hipMemset(sa->d_la_mark, 0, K));
+				HIPCHK(hipMalloc(&sa->d_la_list, sizeof(uint32_t) * K));
+				HIPCHK(hipMalloc(&sa->d_la_hdr, sizeof(uint32_t) * 2));
+				HIPCHK(hipMemset(sa->d_la_hdr, 0, sizeof(uint32_t) * 2));
+				int plo = 0, phi = 0;
+				HIPCHK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+				HIPCHK(hipStreamCreateWithPriority(&sa->stream5, hipStreamDefault, plo));
+				HIPCHK(hipStreamCreateWithPriority(&sa->stream6, hipStreamDefault, plo));
+				HIPCHK(hipEventCreateWithFlags(&sa->ev_redo, hipEventDisableTiming));
+				HIPCHK(hipEventCreateWithFlags(&sa->ev_la_check, hipEventDisableTiming));
+				HIPCHK(hipEventCreateWithFlags(&sa->ev_la_zero, hipEventDisableTiming));
+				for (int i = 0; i < 8; i++) HIPCHK(hipEventCreateWithFlags(&sa->ev_spec[i], hipEventDisableTiming));
+			}
 		}
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
 		sa->form_single = !sa->split_nbr; /* one-kernel form only, or the split form until the device recommends otherwise */
@@ -1055,6 +1209,8 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	const DecideArgs dargs = decide_args(sa);
 	const int mode = (sa->incremental && sa->parallel_build) ? sa->accept_mode : MGL_ACCEPT_SINGLE; /* bulk steps rebuild with the parallel builder */
 	sa->mode_log.clear();
+	sa->la_ready = false;
+	const bool la_ok = sa->la_enabled && inc_apply && sa->split_nbr && sa->ctx.diag_stop == 0;
 	uint64_t imp_seen = before.imp_cands, acc_seen = before.accepted, last_block = 0;
 	const uint64_t rollbacks_before = sa->bulk_rollbacks;
 	bool last_bulk = false;
@@ -1071,7 +1227,16 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			const bool t = s < timed_steps;
 			sa->mode_log.push_back(bulk ? 1 : 0);
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
-			if ((rc = launch_neighbours(sa, ~0ull, s == 0 || !inc_apply))) return rc;
+			/* look-ahead: this step's pick + walk may have run beside the previous step's tail, into the other buffer set */
+			const bool from_la = sa->la_ready;
+			if (from_la) {
+				const mgl_sa::NbrSet now = cur_set(sa);
+				use_set(sa, sa->alt);
+				sa->alt = now;
+				sa->la_ready = false;
+			}
+			if ((rc = launch_neighbours(sa, ~0ull, (s == 0 && !from_la) || !inc_apply, from_la))) return rc;
+			if (la_ok && !bulk && !sa->form_single && s + 1 < e && (rc = launch_lookahead(sa, before.gstep + s + 1, from_la))) return rc;
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
 			if (bulk) {
 				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
@@ -1083,6 +1248,8 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			HIPCHK(hipGetLastError());
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
 			if (inc_apply) {
+				/* the accept changes the base: the speculative pick + walk of the next step read it until they are through */
+				if (sa->la_ready) for (uint32_t h = 0; h < nbr_slices(sa); h++) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_spec[h], 0));
 				if ((rc = launch_apply(sa))) return rc;
 			} else {
 				hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,

@@ -210,6 +210,7 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 			if (ctl->cur_cost != cost) atomicOr(&ctl->error_flags, MGL_ERR_REBUILD_MISMATCH);
 			ctl->accepted_flag = 0;
 			ctl->full_rebuilds++;
+			ctl->mod_lo = 0u; ctl->mod_hi = MGL_POS_INF; /* look-ahead: nothing evaluated ahead of this rebuild is kept */
 		}
 	}
 }
@@ -665,6 +666,11 @@ struct BigScratch {
 	uint32_t lds_cache; /* second pass: 12 * MGL_BIG_CAP bytes of LDS behind the wavefront's area hold a copy of the lists during a re-simulation */
 	uint16_t* sim_keys; /* per neighbour: ins_key[chg_cap] | rem_key[chg_cap] */
 	uint32_t* sim_pos;  /* per neighbour: ins_pos[chg_cap] | rem_pos[chg_cap] */
+	/* look-ahead (mgl_kernels4.hip:k_la_check): the regular launch over a list of neighbours instead of a slice, and the
+	 * second pass skipping list entries of the speculative launch that the check took back */
+	const uint32_t* la_list; const uint32_t* la_count;
+	const uint8_t* la_mark; const uint32_t* la_spec_count;
+	const uint32_t* todo_first; /* second pass over the list's tail only: entries from *todo_first on (nullptr: all) */
 };
 /* MODE: the regular launch is split in two so that each half needs fewer registers and more
  * wavefronts fit a SIMD (top-K is the register hog):
@@ -691,11 +697,15 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	uint32_t j = j_base + unit; /* [j_base, j_end): the slice of the step this launch covers */
 	uint32_t slot = 0;
 	const unsigned long long t_begin = prof_acc ? __builtin_readcyclecounter() : 0ull;
+	if (!BIG && big.la_list != nullptr) j = uni(big.la_list[unit]); /* the launch covers a list (look-ahead: the neighbours evaluated again) */
 	if (BIG) {
-		slot = unit;
+		slot = unit + (big.todo_first != nullptr ? *big.todo_first : 0u);
 		const uint32_t nflag = *big.todo_in_count;
 		if (slot >= nflag) return;
 		j = uni(big.todo_in[slot]);
+		/* an entry the speculative launch made for a neighbour that was evaluated again since: that evaluation speaks for it */
+		if (big.la_mark != nullptr && slot < *big.la_spec_count && j < K && big.la_mark[j]) return;
+		if (lane == 0) atomicAdd((unsigned long long*)&ctl->big_nbrs, 1ull); /* counted where the second pass takes it up */
 	}
 	if (j >= K || (!BIG && j >= j_end)) return;
 	/* LDS per wavefront: [journal | context bitmap | union].  The union holds EITHER the model +
@@ -858,6 +868,8 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			if ((ch.n_ins + ch.n_rem) != 0 && !spilled) {
 				/* the model is about to overwrite the live lists (they share LDS): move the lists to a
 				 * global scratch slot and carry on from there */
+				/* look-ahead's fresh evaluations run beside the second pass, which owns the scratch slots by list index: no spill, next pass */
+				if (!BIG && big.la_list != nullptr) { ch.overflow = true; phase = P_OUT; continue; }
 				uint32_t sl = 0;
 				if (lane == 0) sl = atomicAdd(big.spill_ctr, 1u);
 				sl = uni(sl);
@@ -939,6 +951,10 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 				return;
 			}
 			if (pick_is_mutation) {
+				/* evaluated again by the one-kernel form (look-ahead): the second pass, should this neighbour reach it, takes the
+				 * mutation's pick from the record like every other neighbour of a split step */
+				if (MODE == MGL_NBR_FULL && !BIG && big.la_list != nullptr && pickrec != nullptr && lane == 0)
+					pickrec[j] = make_uint4((uint32_t)picked, (uint32_t)(picked >> 32), rng.n, ok ? 1u : 0u);
 				if (!ok) { generate_failed = true; phase = P_OUT; continue; }
 				m_first = picked;
 				journal_set(jn, pos, first, m_first, lane);
@@ -1108,7 +1124,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		if (lane == 0) {
 			const uint32_t slot2 = atomicAdd(todo_count, 1u);
 			todo[slot2] = j;
-			atomicAdd((unsigned long long*)(BIG ? &ctl->fallback_nbrs : &ctl->big_nbrs), 1ull);
+			if (BIG) atomicAdd((unsigned long long*)&ctl->fallback_nbrs, 1ull);
 			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_NONE;
 		}
 		return;
@@ -1141,7 +1157,8 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	 * chosen form is launched.  The second pass is launched with a small grid whatever its list holds -- the
 	 * host does not know the count -- and strides over it; with an empty list a workgroup costs one load. */
 	const uint32_t waves = blockDim.x >> 6;
-	if (BIG && blockIdx.x * waves >= *big.todo_in_count) return;
+	if (BIG && blockIdx.x * waves + (big.todo_first != nullptr ? *big.todo_first : 0u) >= *big.todo_in_count) return;
+	if (!BIG && big.la_list != nullptr && blockIdx.x * waves >= *big.la_count) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block); the second
@@ -1152,9 +1169,14 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	}
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	if (BIG) {
-		const uint32_t n = *big.todo_in_count;
+		const uint32_t first = big.todo_first != nullptr ? *big.todo_first : 0u;
+		const uint32_t n = *big.todo_in_count > first ? *big.todo_in_count - first : 0u;
 		for (uint32_t unit = blockIdx.x * waves + wid; unit < n; unit += gridDim.x * waves)
 			nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T, unit, lane, wid);
+	} else if (big.la_list != nullptr) {
+		const uint32_t n = *big.la_count;
+		for (uint32_t unit = blockIdx.x * waves + wid; unit < n; unit += gridDim.x * waves)
+			nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, 0u, K, pickstate, smem, T, unit, lane, wid);
 	} else {
 		nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T,
 		                    blockIdx.x * waves + wid, lane, wid);
@@ -1222,7 +1244,6 @@ __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control
 		if (threadIdx.x == 0) {
 			const uint32_t slot2 = atomicAdd(todo_count, 1u);
 			todo[slot2] = j;
-			atomicAdd((unsigned long long*)&ctl->big_nbrs, 1ull);
 			out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j + 1u] = MGL_WIN_NONE;
 		}
 		return;
@@ -1256,7 +1277,11 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b
 	sh.T = T; sh.dyn = s_dyn; sh.sum = s_sum; sh.nu_many = s_nm;
 	if (list) {
 		const uint32_t n = *list_count;
-		for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) sim_one<true>(c, b, ctl, out, big, big.sim_hdr2, list[i], todo, todo_count, sh);
+		for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+			/* look-ahead: an entry of the speculative launch whose neighbour was evaluated again -- the second pass skipped it, its header is stale */
+			if (big.la_mark != nullptr && i < *big.la_spec_count && big.la_mark[list[i]]) continue;
+			sim_one<true>(c, b, ctl, out, big, big.sim_hdr2, list[i], todo, todo_count, sh);
+		}
 	} else {
 		sim_one<false>(c, b, ctl, out, big, big.sim_hdr, j_base + blockIdx.x, todo, todo_count, sh);
 	}

@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 	__shared__ mgl_pk s_jnew[MGL_MAX_DIFFS];
 	__shared__ uint32_t s_ctxbits[512]; /* up to 16384 contexts */
 	const uint32_t lane = threadIdx.x;
+	if (lane == 0) { ctl->mod_lo = MGL_POS_INF; ctl->mod_hi = 0u; }
 	if (!ctl->accepted_flag) return;
 	const uint32_t winner = ctl->winner;
 	const uint32_t nd = out.ndiffs[winner];
@@ -629,6 +630,7 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 		/* ---- 4. dense checkpoints: this context's value wherever its trajectory changed */
 		for (uint32_t sg = 0; sg < s_nseg; sg++) {
 			const uint32_t lo = s_seg_lo[sg], hi = s_seg_hi[sg];
+			if (tid == 0) { atomicMin(&ctl->mod_lo, lo); atomicMax(&ctl->mod_hi, hi); }
 			const uint32_t first = s_seg_first[sg], last = s_seg_last[sg];
 			/* a boundary can lie behind a packet that starts up to 272 bytes before lo */
 			const uint32_t ck_lo = (lo > MGL_MAX_MATCH ? lo - MGL_MAX_MATCH : 0u) >> MGL_CK2_SHIFT;

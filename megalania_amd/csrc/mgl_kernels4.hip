@@ -109,6 +109,8 @@ __global__ void __launch_bounds__(1024) k_decide(DevCtx c, BaseView b, Control* 
 		ctl->accepted_flag = winner != ~0u;
 		ctl->copy_best_flag = 0;
 		ctl->taken = winner != ~0u ? 1u : 0u;
+		ctl->la_lo = winner != ~0u ? out.win[2u * winner] : MGL_POS_INF; /* for the look-ahead's check of the next step */
+		ctl->la_end = winner != ~0u ? out.win[2u * winner + 1u] : 0u;
 		ctl->cur_cost = base_cost; /* an epoch's current cost starts as the exact cost of its first slab */
 		if (winner != ~0u) {
 			ctl->accepted++;
@@ -319,4 +321,70 @@ __global__ void __launch_bounds__(256) k_bulk_rollback(NbrOut out, BulkBuf bb, m
 __global__ void k_bulk_reset(BulkBuf bb)
 {
 	if (threadIdx.x == 0 && blockIdx.x == 0) bb.hdr[1] = 0;
+}
+
+/* ================================================================== look-ahead
+ *
+ * While a step's re-simulations, second pass, decision and accept run (few wavefronts, one long dependency chain), the
+ * first two thirds of the NEXT step's evaluation -- pick and window walk, which do not price anything -- run beside
+ * them on the base as it is before the accept.  After the accept k_la_check keeps every such result that the accepted
+ * move cannot have touched and lists the others for a fresh evaluation:
+ *   - the target draw is repeated on the new on-walk bitmap (same draws; a draw inside the accepted window may land
+ *     differently now);
+ *   - a neighbour wholly in front of the accepted window (its walk met the base again at or before the window's first
+ *     position) saw only unchanged packets, and the model at its target is the old one;
+ *   - a neighbour whose target lies at or behind the window's end starts from the same walk state (that is what the end
+ *     means) and reads unchanged packets; its pick is kept iff no context's probability before its target changed:
+ *     target outside (mod_lo, mod_hi], the span k_apply_chains reports (first change .. last re-coupling over all contexts);
+ *   - anything else is evaluated again.
+ * What is kept is bit for bit what a launch after the accept would have produced: the walk and the change lists hold
+ * positions, packets and contexts only; costs come from k_sim, which runs after the accept either way. */
+__global__ void __launch_bounds__(256) k_la_check(DevCtx c, Base2 b, const Control* ctl, NbrOut out, const uint4* pickstate, uint4* sim_hdr,
+                                                  const uint32_t* todo_count, uint8_t* mark, uint32_t* list, uint32_t* hdr, uint64_t seed, uint32_t K)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+	if (j == 0) hdr[1] = *todo_count; /* second-pass entries made by the speculative launch: [0, this) */
+	bool redo = false;
+	const uint32_t a_lo = ctl->la_lo, a_end = ctl->la_end;
+	if (j < K && a_lo != MGL_POS_INF) {
+		const uint4 s0 = pickstate[2u * j];
+		const uint32_t target = s0.x, rn = s0.y;
+		/* the draw of mgl_kernels2.hip:nbr2_one, one thread instead of 32 lanes */
+		const uint64_t key = mgl_rng_key(seed, ctl->gstep, j);
+		uint32_t t2 = 0, rn2 = 32, last = 0;
+		bool hit = false;
+		for (uint32_t i = 0; i < 32 && !hit; i++) {
+			last = mgl_rng_draw(key, i) % c.n;
+			if ((b.onwalk[last >> 6] >> (last & 63u)) & 1ull) { hit = true; t2 = last; rn2 = i + 1u; }
+		}
+		if (!hit) {
+			uint32_t wd = last >> 6;
+			uint64_t bits = b.onwalk[wd] & (~0ull << (last & 63u));
+			while (!bits && ++wd < b.nw0) bits = b.onwalk[wd];
+			t2 = bits ? (wd << 6) + ctz64(bits) : 0u;
+		}
+		if (t2 != target || rn2 != rn) redo = true;
+		else if (target < a_lo) {
+			const uint32_t wend = out.win[2u * j + 1u];
+			if (target > ctl->mod_lo) redo = true;                          /* (a full rebuild reports everything as changed) */
+			else if (wend == MGL_WIN_DROPPED) redo = true;                  /* given up on the way: how far it got is not recorded */
+			else if (wend != MGL_WIN_NONE && wend > a_lo) redo = true;      /* walked into the accepted window */
+		} else {
+			const uint32_t m_lo = ctl->mod_lo, m_hi = ctl->mod_hi;
+			if (target < a_end) redo = true;
+			else if (target > m_lo && target <= m_hi) redo = true;
+		}
+	}
+	if (j < K) mark[j] = redo ? 1u : 0u;
+	const unsigned long long m = __ballot(redo);
+	if (m) {
+		unsigned long long base = 0;
+		const int first = __ffsll((long long)m) - 1;
+		if ((int)lane == first) base = atomicAdd(&hdr[0], (uint32_t)__popcll(m));
+		base = (unsigned long long)shfl64(base, first);
+		if (redo) {
+			list[(uint32_t)base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+			sim_hdr[j].x = 0xFFFFFFFFu; /* the regular re-simulation launch passes it by */
+		}
+	}
 }

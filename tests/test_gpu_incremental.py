@@ -306,6 +306,38 @@ def test_launch_forms_give_one_trajectory(monkeypatch):
         x.close()
 
 
+@pytest.mark.parametrize("name,size,K,cap", [("lorem", 4096, 64, 0), ("enwik", 200000, 2048, 0), ("enwik_small_lists", 60000, 1024, 16)])
+def test_look_ahead_gives_the_same_trajectory(monkeypatch, name, size, K, cap):
+    """MGL_LOOKAHEAD=1 (opt-in): the next step's pick + window walk run beside this step's tail on the base as it is before
+    the accept; k_la_check keeps what the accepted move cannot have touched and has the rest evaluated again.  Whatever is
+    kept or redone, the chain must be the one the plain order produces: same statistics block by block (look-ahead works
+    inside a mgl_sa_run call), same slab -- also with the first-pass lists shrunk so that the second pass sees entries from
+    both the speculative launch and the fresh evaluations."""
+    data = corpus.lorem(size) if name == "lorem" else corpus.enwik_like(size, 0x4C41)
+    monkeypatch.setenv("MGL_NO_ADAPT", "1")  # the split form throughout: look-ahead only exists there
+    monkeypatch.delenv("MGL_LOOKAHEAD", raising=False)
+    plain = binding.SA(data, accept="single", neighbours_per_step=K, seed=77, iters_per_epoch=10**7)
+    monkeypatch.setenv("MGL_LOOKAHEAD", "1")
+    ahead = binding.SA(data, accept="single", neighbours_per_step=K, seed=77, iters_per_epoch=10**7)
+    monkeypatch.delenv("MGL_LOOKAHEAD")
+    if cap:
+        for x in (plain, ahead):
+            assert x.L.mgl_debug_set(x.h, 2, cap) == 0
+    accepted = 0
+    for chunk in (1, 2, 3, 8, 30, 64, 70):
+        a, b = plain.run(chunk), ahead.run(chunk)
+        for k in ("evaluations", "accepted", "improved", "current_cost", "best_cost", "packets", "failed", "dropped_neighbours"):
+            assert a[k] == b[k], (chunk, k)
+        accepted += a["accepted"]
+    ca, _ = plain.current()
+    cb, _ = ahead.current()
+    assert (ca == cb).all() and accepted > 20
+    o = Oracle(data, dict_limit=0x400000)
+    assert ahead.current()[1] == o.cost_slab(cb.astype(literal_slab(1).dtype))["total"]
+    plain.close()
+    ahead.close()
+
+
 def test_second_pass_takes_what_overflows_small_lists():
     """The first-pass change lists are sized by the step (1 024 events each way for small steps), so
     small tests rarely overflow them.  Shrunk to 16 events (mgl_debug_set key 2) most neighbours go

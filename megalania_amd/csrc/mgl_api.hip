@@ -316,6 +316,9 @@ static int launch_apply(mgl_sa* sa)
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
+/* diagnostic (MGL_TRACE=1): name every launch of the neighbour evaluation on stderr and wait for the device after it, so that a
+ * faulting kernel is the last one named */
+#define NBR_TRACE(name) do { if (getenv("MGL_TRACE")) { fprintf(stderr, "[mgl] %s\n", name); hipError_t e_ = hipDeviceSynchronize(); if (e_ != hipSuccess) fprintf(stderr, "[mgl] %s -> %s\n", name, hipGetErrorString(e_)); } } while (0)
 static mgl_sa::NbrSet cur_set(const mgl_sa* sa)
 {
 	mgl_sa::NbrSet t = { sa->nbr, sa->d_pickrec, sa->d_pickstate, sa->big.sim_hdr, sa->big.sim_keys, sa->big.sim_pos, sa->d_todo, sa->d_counts };
@@ -347,10 +350,10 @@ static int launch_pick_rest(mgl_sa* sa, const mgl_sa::NbrSet& t, uint64_t step_o
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_PICK>), dim3((j1 - j0 + sa->pick_waves - 1) / sa->pick_waves), dim3(64 * sa->pick_waves),
 		                   4096u + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, t.nbr, sa->per_wave_pick, t.todo, t.counts,
-		                   (unsigned long long*)nullptr, g, t.pickrec, j0, j1, t.pickstate);
+		                   (unsigned long long*)nullptr, g, t.pickrec, j0, j1, t.pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_PICK>");
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), sa->per_wave_rest, st, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, t.nbr, sa->per_wave_rest, t.todo, t.counts,
-		                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, g, t.pickrec, j0, j1, t.pickstate);
+		                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, g, t.pickrec, j0, j1, t.pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_REST>");
 		HIPCHK(hipEventRecord(done[h], st));
 	}
 	HIPCHK(hipGetLastError());
@@ -378,7 +381,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 		const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 		hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 		                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
-		                   (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+		                   (const uint32_t*)nullptr, (const uint32_t*)nullptr); NBR_TRACE("k_neighbours");
 		HIPCHK(hipGetLastError());
 		return MGL_OK;
 	}
@@ -402,7 +405,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			 * move cannot have touched, evaluate the others again in the one-kernel form (a list, usually short) */
 			HIPCHK(hipMemsetAsync(sa->d_la_hdr, 0, 2 * sizeof(uint32_t), sa->stream));
 			hipLaunchKernelGGL(k_la_check, dim3((K + 255u) / 256u), dim3(256), 0, sa->stream, sa->ctx, sa->b2, (const Control*)sa->base.ctl, sa->nbr,
-			                   (const uint4*)sa->d_pickstate, sa->big.sim_hdr, (const uint32_t*)sa->d_counts, sa->d_la_mark, sa->d_la_list, sa->d_la_hdr, sa->cfg.seed, K);
+			                   (const uint4*)sa->d_pickstate, sa->big.sim_hdr, (const uint32_t*)sa->d_counts, sa->d_la_mark, sa->d_la_list, sa->d_la_hdr, sa->cfg.seed, K); NBR_TRACE("k_la_check");
 			HIPCHK(hipEventRecord(sa->ev_la_check, sa->stream));
 			HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_la_check, 0));
 			HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_la_check, 0));
@@ -413,7 +416,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
 			if (!from_lookahead) HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
 			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
-			                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+			                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr); NBR_TRACE("k_sim");
 		}
 		HIPCHK(hipEventRecord(sa->ev_sim, sa->stream3));
 		if (!from_lookahead) {
@@ -423,16 +426,16 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			g.la_list = sa->d_la_list; g.la_count = sa->d_la_hdr;
 			const uint32_t grid = blocks2 < 4096u ? blocks2 : 4096u; /* strides over the list */
 			/* on the second stream, beside the second pass over the speculative launch's entries; its own entries get a second pass of their own below */
-			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(grid), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream2, sa->ctx,
+			hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL, true>), dim3(grid), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream2, sa->ctx,
 			                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
-			                   sa->d_prof, g, sa->d_pickrec, 0u, K, sa->d_pickstate);
+			                   sa->d_prof, g, sa->d_pickrec, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_FULL, true>");
 			HIPCHK(hipEventRecord(sa->ev_redo, sa->stream2));
 		}
 	}
 	if (!sa->split_nbr || sa->form_single) { /* the one-kernel form */
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_FULL>), dim3(blocks2), dim3(64 * sa->waves_per_block2), sa->nbr2_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo, sa->d_counts,
-		                   sa->d_prof, sa->big, sa->d_pickrec, 0u, K, sa->d_pickstate);
+		                   sa->d_prof, sa->big, sa->d_pickrec, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_FULL>");
 	}
 	/* the few whose change lists overflowed LDS (or that need a second top-K pick): the whole
 	 * evaluation in one kernel, lists in global scratch */
@@ -448,37 +451,43 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 		big_now.la_mark = sa->d_la_mark; big_now.la_spec_count = sa->d_la_hdr + 1;
 		big_now.todo_in_count = sa->d_la_hdr + 1;
 	}
-	hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
-	                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-	                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate);
+	if (la_step) {
+		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL, true>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
+		                   (unsigned long long*)nullptr, big_now, sa->d_pickrec, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL, true>");
+	} else {
+		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
+		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
+		                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL>");
+	}
 	if (la_step) {
 		/* ... then, once the fresh evaluations are through, the entries they added */
 		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_redo, 0));
 		big_now.todo_in_count = sa->d_counts;
 		big_now.todo_first = sa->d_la_hdr + 1;
-		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 256u ? bigblocks : 256u), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
+		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL, true>), dim3(bigblocks < 256u ? bigblocks : 256u), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-		                   (unsigned long long*)nullptr, big_now, sa->d_pickrec, 0u, K, sa->d_pickstate);
+		                   (unsigned long long*)nullptr, big_now, sa->d_pickrec, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL, true>");
 		big_now.todo_first = nullptr;
 	}
 	if (split_now) {
 		/* the second pass handed its final re-simulations to k_sim as well (headers in sim_hdr2): a small grid over its list */
 		const uint32_t sim_lds = ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + MGL_SIM2_CAP * 16u;
-		hipLaunchKernelGGL(k_sim, dim3(256), dim3(64 * MGL_SIM_WAVES), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, big_now, 0u, K,
-		                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts);
+		hipLaunchKernelGGL(k_sim, dim3(256), dim3(64 * MGL_SIM_WAVES_LIST), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, big_now, 0u, K,
+		                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts); NBR_TRACE("k_sim");
 		/* what k_sim (either launch) could not take: a late second pass that re-simulates inline */
 		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 		BigScratch late = sa->big;
 		late.todo_in = sa->d_todo3; late.todo_in_count = sa->d_counts + 4; late.sim_hdr2 = nullptr; late.lds_cache = 1u;
 		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 64u ? bigblocks : 64u), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-		                   (unsigned long long*)nullptr, late, sa->d_pickrec, 0u, K, sa->d_pickstate);
+		                   (unsigned long long*)nullptr, late, sa->d_pickrec, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL>");
 	}
 	/* and whatever overflowed even that: exact full walk from byte 0 (a small grid strides over the list) */
 	const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
 	hipLaunchKernelGGL(k_neighbours, dim3(blocks < 256u ? blocks : 256u), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
 	                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
-	                   (const uint32_t*)sa->d_todo2, (const uint32_t*)(sa->d_counts + 1));
+	                   (const uint32_t*)sa->d_todo2, (const uint32_t*)(sa->d_counts + 1)); NBR_TRACE("k_neighbours");
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -847,9 +856,11 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		HIPCHK(hipMemset(sa->d_todo3, 0, sizeof(uint32_t) * (K + 1)));
 		sa->big.todo_in = sa->d_todo; sa->big.todo_in_count = sa->d_counts; sa->big.spill_ctr = sa->d_counts + 2;
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_FULL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_PICK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<false, MGL_NBR_REST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->nbr2_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sa->nbr2_lds + 12u * MGL_BIG_CAP)));
+		HIPCHK(hipFuncSetAttribute((const void*)k_neighbours2<true, MGL_NBR_FULL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sa->nbr2_lds + 12u * MGL_BIG_CAP)));
 		HIPCHK(hipMalloc(&sa->d_pickrec, sizeof(uint4) * K));
 		HIPCHK(hipMalloc(&sa->d_pickstate, sizeof(uint4) * 2 * K));
 		sa->split_nbr = getenv("MGL_NO_SPLIT") == nullptr;

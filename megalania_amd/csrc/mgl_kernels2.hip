@@ -687,7 +687,7 @@ struct BigScratch {
 #define MGL_NBR_REST 2
 /* one neighbour, by the wavefront `wid` of its workgroup; `unit` = the neighbour's index in this launch's slice
  * (regular launch) or its slot in the second pass's list (BIG) */
-template <bool BIG, int MODE>
+template <bool BIG, int MODE, bool LIST>
 __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Control* ctl, uint64_t seed,
                                          uint64_t step_override, uint32_t K, const NbrOut& out, uint32_t per_wave_bytes,
                                          uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
@@ -697,14 +697,14 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	uint32_t j = j_base + unit; /* [j_base, j_end): the slice of the step this launch covers */
 	uint32_t slot = 0;
 	const unsigned long long t_begin = prof_acc ? __builtin_readcyclecounter() : 0ull;
-	if (!BIG && big.la_list != nullptr) j = uni(big.la_list[unit]); /* the launch covers a list (look-ahead: the neighbours evaluated again) */
+	if (!BIG && LIST) j = uni(big.la_list[unit]); /* the launch covers a list (look-ahead: the neighbours evaluated again) */
 	if (BIG) {
-		slot = unit + (big.todo_first != nullptr ? *big.todo_first : 0u);
+		slot = unit + ((LIST && big.todo_first != nullptr) ? *big.todo_first : 0u);
 		const uint32_t nflag = *big.todo_in_count;
 		if (slot >= nflag) return;
 		j = uni(big.todo_in[slot]);
 		/* an entry the speculative launch made for a neighbour that was evaluated again since: that evaluation speaks for it */
-		if (big.la_mark != nullptr && slot < *big.la_spec_count && j < K && big.la_mark[j]) return;
+		if (LIST && big.la_mark != nullptr && slot < *big.la_spec_count && j < K && big.la_mark[j]) return;
 		if (lane == 0) atomicAdd((unsigned long long*)&ctl->big_nbrs, 1ull); /* counted where the second pass takes it up */
 	}
 	if (j >= K || (!BIG && j >= j_end)) return;
@@ -869,7 +869,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 				/* the model is about to overwrite the live lists (they share LDS): move the lists to a
 				 * global scratch slot and carry on from there */
 				/* look-ahead's fresh evaluations run beside the second pass, which owns the scratch slots by list index: no spill, next pass */
-				if (!BIG && big.la_list != nullptr) { ch.overflow = true; phase = P_OUT; continue; }
+				if (!BIG && LIST) { ch.overflow = true; phase = P_OUT; continue; }
 				uint32_t sl = 0;
 				if (lane == 0) sl = atomicAdd(big.spill_ctr, 1u);
 				sl = uni(sl);
@@ -953,7 +953,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 			if (pick_is_mutation) {
 				/* evaluated again by the one-kernel form (look-ahead): the second pass, should this neighbour reach it, takes the
 				 * mutation's pick from the record like every other neighbour of a split step */
-				if (MODE == MGL_NBR_FULL && !BIG && big.la_list != nullptr && pickrec != nullptr && lane == 0)
+				if (!BIG && LIST && pickrec != nullptr && lane == 0)
 					pickrec[j] = make_uint4((uint32_t)picked, (uint32_t)(picked >> 32), rng.n, ok ? 1u : 0u);
 				if (!ok) { generate_failed = true; phase = P_OUT; continue; }
 				m_first = picked;
@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		                   ((unsigned long long)((ch.n_ins + ch.n_rem) & 0xFFFu) << 40) | ((unsigned long long)(walked & 0xFFFu) << 52);
 }
 
-template <bool BIG, int MODE>
+template <bool BIG, int MODE, bool LIST = false>
 __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? (BIG ? 1 : MGL_NBR_WAVES_PER_SIMD) : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
@@ -1157,8 +1157,8 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	 * chosen form is launched.  The second pass is launched with a small grid whatever its list holds -- the
 	 * host does not know the count -- and strides over it; with an empty list a workgroup costs one load. */
 	const uint32_t waves = blockDim.x >> 6;
-	if (BIG && blockIdx.x * waves + (big.todo_first != nullptr ? *big.todo_first : 0u) >= *big.todo_in_count) return;
-	if (!BIG && big.la_list != nullptr && blockIdx.x * waves >= *big.la_count) return;
+	if (BIG && blockIdx.x * waves + ((LIST && big.todo_first != nullptr) ? *big.todo_first : 0u) >= *big.todo_in_count) return;
+	if (!BIG && LIST && blockIdx.x * waves >= *big.la_count) return;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t* T = (uint16_t*)smem;
 	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block); the second
@@ -1169,16 +1169,16 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	}
 	const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
 	if (BIG) {
-		const uint32_t first = big.todo_first != nullptr ? *big.todo_first : 0u;
+		const uint32_t first = (LIST && big.todo_first != nullptr) ? *big.todo_first : 0u;
 		const uint32_t n = *big.todo_in_count > first ? *big.todo_in_count - first : 0u;
 		for (uint32_t unit = blockIdx.x * waves + wid; unit < n; unit += gridDim.x * waves)
-			nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T, unit, lane, wid);
-	} else if (big.la_list != nullptr) {
+			nbr2_one<BIG, MODE, LIST>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T, unit, lane, wid);
+	} else if (LIST) {
 		const uint32_t n = *big.la_count;
 		for (uint32_t unit = blockIdx.x * waves + wid; unit < n; unit += gridDim.x * waves)
-			nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, 0u, K, pickstate, smem, T, unit, lane, wid);
+			nbr2_one<BIG, MODE, true>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, 0u, K, pickstate, smem, T, unit, lane, wid);
 	} else {
-		nbr2_one<BIG, MODE>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T,
+		nbr2_one<BIG, MODE, false>(c, b, ctl, seed, step_override, K, out, per_wave_bytes, todo, todo_count, prof_acc, big, pickrec, j_base, j_end, pickstate, smem, T,
 		                    blockIdx.x * waves + wid, lane, wid);
 	}
 }
@@ -1192,8 +1192,12 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
  * wavefront (the mean one lives a third of that), and the slowest are the ones with many contexts.
  * Small kernel: no walk state, no journal -- 64 VGPRs less than the second half. */
 #ifndef MGL_SIM_WAVES
-#define MGL_SIM_WAVES 2u
+#define MGL_SIM_WAVES 2u   /* the regular launch: thousands of neighbours, a hundred contexts each */
 #endif
+#ifndef MGL_SIM_WAVES_LIST
+#define MGL_SIM_WAVES_LIST 8u /* the second pass's few neighbours (long lists, hundreds of contexts): one trip over the contexts */
+#endif
+#define MGL_SIM_WAVES_MAX 8u
 struct SimShared {
 	uint16_t* T;
 	uint32_t* dyn;
@@ -1249,27 +1253,27 @@ __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control
 		return;
 	}
 	if (c.diag_stop == 41) { if (threadIdx.x == 0) out.cost[j] = sh.nu_many[0]; return; } /* diagnostic: listing only */
-	const int64_t mine = chain_sim_contexts(b, ch, sh.T, MGL_POS_INF, nullptr, lane, wid * 64u, 64u * MGL_SIM_WAVES, sh.nu_many[0]);
+	const int64_t mine = chain_sim_contexts(b, ch, sh.T, MGL_POS_INF, nullptr, lane, wid * 64u, blockDim.x, sh.nu_many[0]);
 	const uint64_t u = wave_sum64((uint64_t)mine);
 	if (lane == 0) sh.sum[wid] = u;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint64_t d = 0;
-		for (uint32_t w = 0; w < MGL_SIM_WAVES; w++) d += sh.sum[w];
+		for (uint32_t w = 0; w < (blockDim.x >> 6); w++) d += sh.sum[w];
 		const int64_t direct = (int64_t)((uint64_t)hdr.z | ((uint64_t)hdr.w << 32));
 		out.cost[j] = (uint64_t)((int64_t)ctl->rebuild_cost + (int64_t)d + direct);
 	}
 }
 /* list == nullptr: the regular launch, workgroup x = neighbour j_base + x with header sim_hdr.  list != nullptr: the
  * second pass's neighbours (headers in sim_hdr2), a small grid striding over the list. */
-__global__ void __launch_bounds__(64 * MGL_SIM_WAVES, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
+__global__ void __launch_bounds__(64 * MGL_SIM_WAVES_MAX, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
                                                            uint32_t* todo, uint32_t* todo_count, const uint32_t* list, const uint32_t* list_count)
 {
 	if (list ? blockIdx.x >= *list_count : j_base + blockIdx.x >= j_end) return;
 	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
 	/* sized by the launch: one bit per context, then the two lists (positions, keys) and the context list */
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-	__shared__ unsigned long long s_sum[MGL_SIM_WAVES];
+	__shared__ unsigned long long s_sum[MGL_SIM_WAVES_MAX];
 	__shared__ uint32_t s_nm[2];
 	if (!list && big.sim_hdr[j_base + blockIdx.x].x == 0xFFFFFFFFu) return; /* before the table load: most launches of a bulk-free step's tail */
 	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];

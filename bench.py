@@ -148,7 +148,7 @@ def reference_curve(cfg):
         return json.load(f)
 
 
-def size_gates(binding, data, K, props, cpu, cfg):
+def size_gates(binding, data, K, props, cpu, cfg, accept="auto"):
     """Estimated stream size (18 + perplexity / 16384, main.c:97) of a fresh chain in the default accept mode against
     the reference path's at (a) equal evaluations and (b) equal steps = reference iterations, both stated."""
     pts = []
@@ -162,7 +162,7 @@ def size_gates(binding, data, K, props, cpu, cfg):
         return None
     n = len(data)
     marks = sorted({-(-it // K) for it, _, _ in pts} | {it for it, _, _ in pts if it <= 4096})
-    sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=n, **props)
+    sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=n, accept=accept, **props)
     at, done, evals = {}, 0, 0
     for m in marks:
         st = sa.run(m - done)
@@ -173,7 +173,7 @@ def size_gates(binding, data, K, props, cpu, cfg):
     out = []
     for it, ref_bytes, src in pts:
         s_eq = -(-it // K)
-        row = dict(reference_iterations=it, reference_est_bytes=round(ref_bytes, 1), reference_source=src,
+        row = dict(reference_iterations=it, reference_est_bytes=round(ref_bytes, 1), reference_source=src, accept_mode=accept,
                    equal_evaluations=dict(gpu_steps=s_eq, gpu_evaluations=at[s_eq][1], gpu_est_bytes=round(at[s_eq][0], 1),
                                           gpu_le_reference=at[s_eq][0] <= ref_bytes))
         if it in at:
@@ -420,6 +420,11 @@ def main():
                 sg2 = size_gates(binding, c2, DEFAULT_K["c2"], {}, None, "c2")
                 if sg2:
                     gates["size_vs_reference_c2"] = sg2
+                # the same with every step a bulk step: AUTO goes back to single steps (one accept per 4 096 evaluations) as soon
+                # as that is faster per second, which costs progress per evaluation -- this is the per-evaluation best of the engine
+                sg3 = size_gates(binding, c2, DEFAULT_K["c2"], {}, None, "c2", accept="bulk")
+                if sg3:
+                    gates["size_vs_reference_c2_bulk"] = sg3
         if gates:
             out["gates"] = gates
         print(json.dumps(out), flush=True)

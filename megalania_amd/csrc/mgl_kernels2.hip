@@ -681,6 +681,9 @@ struct BigScratch {
  *                 chain re-simulation.  A repair that needs another top-K pick (rare) hands the
  *                 neighbour to the next pass;
  *   MGL_NBR_FULL  the whole thing in one kernel (the BIG second pass, which starts from scratch). */
+#ifndef MGL_REST_WAVES_PER_SIMD
+#define MGL_REST_WAVES_PER_SIMD 4
+#endif
 #define MGL_SIM2_CAP 4096u /* events per list k_sim's second launch takes (the second pass's neighbours) */
 #define MGL_NBR_FULL 0
 #define MGL_NBR_PICK 1
@@ -1147,7 +1150,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 }
 
 template <bool BIG, int MODE, bool LIST = false>
-__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? (BIG ? 1 : MGL_NBR_WAVES_PER_SIMD) : 4)) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
+__global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MGL_NBR_FULL ? (BIG ? 1 : MGL_NBR_WAVES_PER_SIMD) : (MODE == MGL_NBR_REST ? MGL_REST_WAVES_PER_SIMD : 4))) k_neighbours2(DevCtx c, Base2 b, Control* ctl, uint64_t seed,
                                                      uint64_t step_override, uint32_t K, NbrOut out, uint32_t per_wave_bytes,
                                                      uint32_t* todo, uint32_t* todo_count, unsigned long long* prof_acc,
                                                      BigScratch big, uint4* pickrec, uint32_t j_base, uint32_t j_end, uint4* pickstate)

@@ -348,7 +348,7 @@ static int launch_pick_rest(mgl_sa* sa, const mgl_sa::NbrSet& t, uint64_t step_o
 		const uint32_t j0 = (uint32_t)((uint64_t)K * h / slices), j1 = (uint32_t)((uint64_t)K * (h + 1) / slices);
 		hipStream_t st = (h & 1u) ? s_odd : s_even;
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_PICK>), dim3((j1 - j0 + sa->pick_waves - 1) / sa->pick_waves), dim3(64 * sa->pick_waves),
-		                   4096u + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
+		                   (MGL_PICK_T_GLOBAL ? 0u : 4096u) + sa->pick_waves * sa->per_wave_pick, st, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, t.nbr, sa->per_wave_pick, t.todo, t.counts,
 		                   (unsigned long long*)nullptr, g, t.pickrec, j0, j1, t.pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_PICK>");
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), sa->per_wave_rest, st, sa->ctx,
@@ -929,13 +929,13 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			/* the workgroup size that puts most wavefronts on a CU's 160 KiB (larger models -- lc > 0 -- fit fewer) */
 			uint32_t best_w = 1, best_resident = 0;
 			for (uint32_t w = 1; w <= 8; w *= 2) {
-				const uint32_t bytes = 4096u + w * sa->per_wave_pick;
+				const uint32_t bytes = (MGL_PICK_T_GLOBAL ? 0u : 4096u) + w * sa->per_wave_pick;
 				if (bytes > 160u * 1024u) break;
 				const uint32_t resident = (160u * 1024u / ((bytes + 1279u) / 1280u * 1280u)) * w;
 				if (resident > best_resident) { best_resident = resident; best_w = w; }
 			}
 			if (n > (1u << 20)) best_w = 1;
-			if (sa->pick_waves == 0 || 4096u + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = best_w;
+			if (sa->pick_waves == 0 || (MGL_PICK_T_GLOBAL ? 0u : 4096u) + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = best_w;
 		}
 		HIPCHK(hipFuncSetAttribute((const void*)k_sim, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));

@@ -681,6 +681,9 @@ struct BigScratch {
  *                 chain re-simulation.  A repair that needs another top-K pick (rare) hands the
  *                 neighbour to the next pass;
  *   MGL_NBR_FULL  the whole thing in one kernel (the BIG second pass, which starts from scratch). */
+#ifndef MGL_PICK_T_GLOBAL
+#define MGL_PICK_T_GLOBAL 1 /* the pick half reads the 4 KiB cost table through the vector cache instead of keeping a copy in LDS: 16 instead of 11 wavefronts per CU at 10 MB (c3 neighbour kernels - 5 %), no change at 100 KB */
+#endif
 #ifndef MGL_REST_WAVES_PER_SIMD
 #define MGL_REST_WAVES_PER_SIMD 4
 #endif
@@ -716,7 +719,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	 * lists only start to fill once the mutated packet is known.  A repair that needs another
 	 * top-K pick while the lists are live is handed to the BIG pass, whose lists are in global
 	 * memory.  This keeps 11 instead of 8 wavefronts per CU. */
-	unsigned char* mine = smem + (MODE == MGL_NBR_REST ? 0u : 4096u) + (size_t)wid * per_wave_bytes;
+	unsigned char* mine = smem + ((MODE == MGL_NBR_REST || (MODE == MGL_NBR_PICK && MGL_PICK_T_GLOBAL)) ? 0u : 4096u) + (size_t)wid * per_wave_bytes;
 	Journal jn;
 	jn.old = (mgl_pk*)mine;
 	jn.neu = jn.old + MGL_MAX_DIFFS;
@@ -1166,7 +1169,9 @@ __global__ void __launch_bounds__((MODE == MGL_NBR_PICK ? 512 : 64), (MODE == MG
 	uint16_t* T = (uint16_t*)smem;
 	/* 4 KiB as 256 16-byte units (the table is hipMalloc-aligned, T sits at the start of the LDS block); the second
 	 * half of the split form prices nothing (its re-simulation is k_sim's) and has no table: 4 KiB less per workgroup */
-	if (MODE != MGL_NBR_REST) {
+	if (MODE == MGL_NBR_PICK && MGL_PICK_T_GLOBAL) {
+		T = const_cast<uint16_t*>(c.cost_tbl); /* read through the vector cache: 4 KiB less LDS per pick workgroup */
+	} else if (MODE != MGL_NBR_REST) {
 		for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
 		__syncthreads();
 	}

@@ -263,14 +263,14 @@ def main():
     if greedy:
         sa.seed_greedy(greedy)
         _, seed_cost = sa.current()
-        prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, best_cost=seed_cost, greedy_candidates=greedy)
+        prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, bulk_rollbacks=0, best_cost=seed_cost, greedy_candidates=greedy)
     elif args.prepare_steps != 0:
-        prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, best_cost=0)
+        prep = dict(steps=0, evaluations=0, bulk_steps=0, accepted=0, bulk_rollbacks=0, best_cost=0)
         cap = args.prepare_steps if args.prepare_steps > 0 else PREPARE_CAP[cfg]
         chunk = cap if args.prepare_steps > 0 else (64 if n <= (1 << 20) else 128)
         while prep["steps"] < cap:
             p = sa.run(min(chunk, cap - prep["steps"]))
-            for k in ("steps", "evaluations", "bulk_steps", "accepted"):
+            for k in ("steps", "evaluations", "bulk_steps", "accepted", "bulk_rollbacks"):
                 prep[k] += p[k]
             prep["best_cost"] = p["best_cost"]
             # over: a chunk with (almost) no bulk step -- around its threshold AUTO still takes the odd block of four
@@ -375,7 +375,7 @@ def main():
         if exchange:
             out["exchange"] = exchange
         if prep:
-            out["prepare"] = {"greedy_candidates": prep.get("greedy_candidates"), "steps": prep["steps"], "seconds": t_prep, "evaluations": prep["evaluations"], "bulk_steps": prep["bulk_steps"],
+            out["prepare"] = {"greedy_candidates": prep.get("greedy_candidates"), "steps": prep["steps"], "seconds": t_prep, "evaluations": prep["evaluations"], "bulk_steps": prep["bulk_steps"], "bulk_rollbacks": prep["bulk_rollbacks"],
                               "moves_accepted": prep["accepted"], "est_bytes_best": 18 + prep["best_cost"] / 16384,
                               "evals_per_s": prep["evaluations"] / t_prep if t_prep > 0 else None}
         gates = {}

@@ -141,6 +141,7 @@ struct mgl_sa {
 	/* look-ahead (k_la_check): the next step's pick + window walk run beside this step's tail into the other buffer set */
 	struct NbrSet { NbrOut nbr; uint4* pickrec; uint4* pickstate; uint4* sim_hdr; uint16_t* sim_keys; uint32_t* sim_pos; uint32_t* todo; uint32_t* counts; };
 	NbrSet alt = {};
+	uint32_t sim_waves = MGL_SIM_WAVES; /* wavefronts per neighbour in the regular re-simulation launch (MGL_SIMW: 1, 2, 4, 8) */
 	bool la_enabled = false, la_ready = false;
 	uint8_t* d_la_mark = nullptr;
 	uint32_t* d_la_list = nullptr;
@@ -415,7 +416,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			/* the second half's re-simulation, several wavefronts per neighbour; a neighbour with more touched contexts
 			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
 			if (!from_lookahead) HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
-			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * MGL_SIM_WAVES), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
+			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * sa->sim_waves), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
 			                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr); NBR_TRACE("k_sim");
 		}
 		HIPCHK(hipEventRecord(sa->ev_sim, sa->stream3));
@@ -916,6 +917,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 				for (int i = 0; i < 8; i++) HIPCHK(hipEventCreateWithFlags(&sa->ev_spec[i], hipEventDisableTiming));
 			}
 		}
+		if (getenv("MGL_SIMW")) { const int w = atoi(getenv("MGL_SIMW")); if (w == 1 || w == 2 || w == 4 || w == 8) sa->sim_waves = (uint32_t)w; }
 		sa->adaptive = sa->split_nbr && getenv("MGL_NO_ADAPT") == nullptr;
 		sa->form_single = !sa->split_nbr; /* one-kernel form only, or the split form until the device recommends otherwise */
 		/* eight pick wavefronts share a cost table per workgroup: 4 KiB + 8 x 9.3 KiB = 78 KiB, two

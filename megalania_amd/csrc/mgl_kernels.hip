@@ -825,7 +825,10 @@ __device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, 
 			const mgl_pk pk = uni64(journal_or_base(jn, slab, p, lane));
 			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk);
 			if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) {
-				wsoft = 0xFFFFFFFFu;
+				/* not when it is the base's own packet reading a slot that holds the same distance in both walks */
+				const uint32_t slot = ntype == MGL_SHORT_REP ? 0u : ndist;
+				const bool same_read = bs.pos == p && uni64(slab[p]) == pk && mgl_dist_at(&nb, slot) == mgl_dist_at(&bs, slot);
+				if (!same_read) wsoft = 0xFFFFFFFFu;
 				dep |= ntype == MGL_SHORT_REP ? (taint & 1u) : ((taint >> ndist) & 1u);
 			}
 			if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;

@@ -1054,8 +1054,12 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					walked++;
 					const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
 					/* which rep distances this packet reads / pushes: bit k of taint = distance k comes from before the window */
-					if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) { /* a rep packet: the soft window reaches at least to behind it */
-						wsoft = 0xFFFFFFFFu;
+					if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) {
+						/* a rep packet: the soft window reaches at least to behind it -- unless it is the base's own packet at this
+						 * position reading a slot that holds the same distance in both walks (the move has no part in what it codes) */
+						const uint32_t slot = ntype == MGL_SHORT_REP ? 0u : ndist;
+						const bool same_read = bs.pos == p && win_pk(win, p) == pk && mgl_dist_at(&nb, slot) == mgl_dist_at(&bs, slot);
+						if (!same_read) wsoft = 0xFFFFFFFFu;
 						dep |= ntype == MGL_SHORT_REP ? (taint & 1u) : ((taint >> ndist) & 1u);
 					}
 					if (ntype == MGL_MATCH) taint = (taint << 1) & 0xFu;

@@ -926,9 +926,13 @@ static window_info window_end(const orc_ctx* c, const orc_packet* slab, const jo
 			wi.walked++;
 			const size_t p = nb.pos;
 			const orc_packet pk = slab[p];
-			/* a rep packet reads the rep distances: the soft window reaches at least to behind it */
+			/* a rep packet reads a rep distance: the soft window reaches at least to behind it -- unless it is the base's own
+			 * packet at this position reading a slot that holds the same distance in both walks (then the move has no part
+			 * in what it codes) */
 			if (pk.type == ORC_SHORT_REP || pk.type == ORC_LONG_REP) {
-				wi.soft_end = (size_t)-1;
+				const unsigned slot = pk.type == ORC_SHORT_REP ? 0u : pk.dist;
+				const int same_read = bs.pos == p && pk_eq(pk, base_at(slab, jn, p)) && nb.dists[slot] == bs.dists[slot];
+				if (!same_read) wi.soft_end = (size_t)-1;
 				wi.dep |= pk.type == ORC_SHORT_REP ? (taint & 1u) : ((taint >> pk.dist) & 1u);
 			}
 			if (pk.type == ORC_MATCH) taint = (taint << 1) & 0xFu;

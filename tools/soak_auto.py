@@ -15,7 +15,7 @@ sa = binding.SA(data, neighbours_per_step=K, iters_per_epoch=len(data), **props)
 chk = binding.SA(data, neighbours_per_step=8, accept="single", **props)
 lcpb = {k: props[k] for k in ("pb",) if k in props}
 done, t0 = 0, time.time()
-tot = dict(bulk_steps=0, accepted=0, dropped_neighbours=0, full_rebuilds=0, fallback_neighbours=0)
+tot = dict(bulk_steps=0, bulk_rollbacks=0, accepted=0, dropped_neighbours=0, full_rebuilds=0, fallback_neighbours=0)
 while done < steps:
     st = sa.run(every); done += every
     for k in tot: tot[k] += st[k]

@@ -265,13 +265,20 @@ static int launch_pbuild(mgl_sa* sa)
 	hipStream_t st = sa->stream;
 	const uint32_t total = c.L.total;
 	hipLaunchKernelGGL(pb_exits, dim3(pb.nblk), dim3(320), 0, st, c, b, pb);
+	hipLaunchKernelGGL(pb_entries_group, dim3(pb.ngrp), dim3(320), MGL_PB_GROUP * MGL_PB_ENTRIES * 2u, st, pb);
 	hipLaunchKernelGGL(pb_entries, dim3(1), dim3(64), 0, st, c, pb);
+	hipLaunchKernelGGL(pb_entries_fill, dim3(pb.ngrp), dim3(64), 0, st, pb);
 	hipLaunchKernelGGL(pb_mark, dim3((pb.nblk + 63) / 64), dim3(64), 0, st, c, b, pb, ctl);
 	hipLaunchKernelGGL(pb_scan, dim3(1), dim3(64), 0, st, pb);
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
 	hipLaunchKernelGGL(pb_walk<false>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
-	hipLaunchKernelGGL(pb_offsets, dim3((b.ck_elems + 255) / 256), dim3(256), 0, st, b, pb, total);
+	{
+		const uint32_t og = (pb.nblk + MGL_PB_OFF_ROWS - 1u) / MGL_PB_OFF_ROWS;
+		hipLaunchKernelGGL(pb_offsets_sum, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb);
+		hipLaunchKernelGGL(pb_offsets_top, dim3((b.ck_elems + 255) / 256), dim3(256), 0, st, b, pb, total, og);
+		hipLaunchKernelGGL(pb_offsets, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb, total);
+	}
 	hipLaunchKernelGGL(pb_layout, dim3(1), dim3(64), 0, st, b, pb, ctl, total);
 	hipLaunchKernelGGL(pb_walk<true>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
 	hipLaunchKernelGGL(pb_sim, dim3((pb.seg_cap + 63) / 64), dim3(64), 0, st, c, b, pb);
@@ -521,12 +528,12 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	free_base(sa->base); free_base(sa->scratch);
 	if (!sa->snapshots) dfree(sa->d_best); /* otherwise it is the best snapshot's slab */
 	dfree(sa->nbr.cost); dfree(sa->nbr.ndiffs); dfree(sa->nbr.walked); dfree(sa->nbr.win); dfree(sa->nbr.win2); dfree(sa->nbr.dpos);
-	dfree(sa->bulk.ckey); dfree(sa->bulk.cwin); dfree(sa->bulk.taken); dfree(sa->bulk.cstate); dfree(sa->bulk.hdr);
+	dfree(sa->bulk.ckey); dfree(sa->bulk.cwin); dfree(sa->bulk.taken); dfree(sa->bulk.cstate); dfree(sa->bulk.cflags); dfree(sa->bulk.hdr);
 	dfree(sa->nbr.dold); dfree(sa->nbr.dnew);
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	free_b2(sa->b2, false);
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
-	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
+	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.gexits); dfree(sa->pb.gentry); dfree(sa->pb.gsum); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
 	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.rep_free); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	{
 		mgl_sa::NbrSet& t = sa->alt;
@@ -701,6 +708,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipMalloc(&sa->bulk.cwin, sizeof(uint4) * K));
 	HIPCHK(hipMalloc(&sa->bulk.taken, sizeof(uint32_t) * K));
 	HIPCHK(hipMalloc(&sa->bulk.cstate, 2u * (size_t)K));
+	HIPCHK(hipMalloc(&sa->bulk.cflags, sizeof(uint32_t) * (size_t)K));
+	HIPCHK(hipMemset(sa->bulk.cflags, 0, sizeof(uint32_t) * (size_t)K));
 	HIPCHK(hipMalloc(&sa->bulk.hdr, sizeof(unsigned long long) * 8));
 	{
 		const unsigned long long h0[8] = { 0, 0, 0, 0, 0, 0, ~0ull, 0 };
@@ -755,6 +764,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			pb.nblk = (uint32_t)((n + (1u << pb.shift) - 1) >> pb.shift);
 			HIPCHK(hipMalloc(&pb.exits, sizeof(uint16_t) * (size_t)pb.nblk * MGL_PB_ENTRIES));
 			HIPCHK(hipMalloc(&pb.entry, sizeof(uint32_t) * ((size_t)pb.nblk + 1)));
+			pb.ngrp = (pb.nblk + MGL_PB_GROUP - 1u) / MGL_PB_GROUP;
+			HIPCHK(hipMalloc(&pb.gexits, sizeof(uint16_t) * (size_t)pb.ngrp * MGL_PB_ENTRIES));
+			HIPCHK(hipMalloc(&pb.gentry, sizeof(uint16_t) * (size_t)pb.ngrp));
+			HIPCHK(hipMalloc(&pb.gsum, sizeof(uint32_t) * (size_t)((pb.nblk + MGL_PB_OFF_ROWS - 1u) / MGL_PB_OFF_ROWS) * ckpt_elems));
 			HIPCHK(hipMalloc(&pb.tf_ctx, sizeof(uint64_t) * pb.nblk));
 			HIPCHK(hipMalloc(&pb.tf_dist, sizeof(uint32_t) * 8 * (size_t)pb.nblk));
 			HIPCHK(hipMalloc(&pb.tf_pk, sizeof(uint32_t) * pb.nblk));
@@ -1171,8 +1184,10 @@ static int launch_bulk_tail(mgl_sa* sa)
 	const DecideArgs a = decide_args(sa);
 	const uint32_t blocks = (K + 255u) / 256u;
 	hipLaunchKernelGGL(k_bulk_prep, dim3(blocks), dim3(256), 0, sa->stream, sa->ctx, sa->base.ctl, sa->nbr, a, sa->bulk);
-	for (uint32_t r = 0; r < MGL_BULK_ROUNDS; r++)
+	for (uint32_t r = 0; r < MGL_BULK_ROUNDS; r++) {
+		hipLaunchKernelGGL(k_bulk_pairs, dim3(blocks, blocks), dim3(256), 0, sa->stream, sa->bulk, K, r);
 		hipLaunchKernelGGL(k_bulk_round, dim3(blocks), dim3(256), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, sa->base.v.slab, K, r);
+	}
 	hipLaunchKernelGGL(k_bulk_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, a);
 	HIPCHK(hipGetLastError());
 	int rc = launch_pbuild(sa);

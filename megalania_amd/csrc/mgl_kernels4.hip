@@ -137,6 +137,7 @@ struct BulkBuf {
 	uint4* cwin;        /* K: their windows: target, end, soft end, dep */
 	uint32_t* taken;    /* K: neighbour indices taken this step */
 	uint8_t* cstate;    /* 2 x K: selection state per candidate (0 undecided, 1 taken, 2 rejected), one array per round parity */
+	uint32_t* cflags;   /* K: what k_bulk_pairs found for each candidate in the current round (zero between rounds) */
 	unsigned long long* hdr; /* [0] acceptable [1] taken [2] valid [3] walked [4] improving [5] dropped [6] smallest taken key */
 };
 
@@ -196,40 +197,51 @@ __device__ __forceinline__ bool windows_conflict(const uint4& x, const uint4& y)
  * (so the result does not depend on scheduling), and what is still undecided after the last round is rejected.
  * The taken ones write their journals into the slab at once (taken windows are pairwise compatible, so no two of
  * them touch one entry). */
-__global__ void __launch_bounds__(256) k_bulk_round(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab, uint32_t K, uint32_t round)
+/* one round, first half: workgroup (x, y) holds the candidates of tile x against the candidates of tile y (256 each) and
+ * ORs what it finds into the candidates' flags -- bit 0: a taken smaller-key candidate conflicts, bit 1: an undecided one
+ * does.  (One workgroup per candidate tile walking all tiles took 3.5 ms per step with 5 000 candidates on 20 CUs.) */
+__global__ void __launch_bounds__(256) k_bulk_pairs(BulkBuf bb, uint32_t K, uint32_t round)
 {
 	__shared__ uint64_t s_key[256];
 	__shared__ uint4 s_win[256];
 	__shared__ uint8_t s_st[256];
 	const uint32_t n = (uint32_t)bb.hdr[0];
-	if (blockIdx.x * blockDim.x >= n) return;
+	if (blockIdx.x * 256u >= n || blockIdx.y * 256u >= n) return;
 	const uint8_t* st_in = bb.cstate + (size_t)(round & 1u) * K;
-	uint8_t* st_out = bb.cstate + (size_t)((round + 1u) & 1u) * K;
-	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t a = blockIdx.x * 256u + threadIdx.x;
 	const bool mine = a < n;
 	const uint8_t my = (mine && round) ? st_in[a] : (uint8_t)0;
-	if (!__syncthreads_or(mine && my == 0)) { if (mine) st_out[a] = my; return; }
-	const uint64_t key = mine ? bb.ckey[a] : 0ull;
-	const uint4 w = mine ? bb.cwin[a] : make_uint4(0u, 0u, 0u, 0u);
-	bool lose = false, blocked = false;
-	for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
-		__syncthreads();
-		if (t0 + threadIdx.x < n) {
-			s_key[threadIdx.x] = bb.ckey[t0 + threadIdx.x]; s_win[threadIdx.x] = bb.cwin[t0 + threadIdx.x];
-			s_st[threadIdx.x] = round ? st_in[t0 + threadIdx.x] : (uint8_t)0;
-		}
-		__syncthreads();
-		const uint32_t cnt = (n - t0) < 256u ? (n - t0) : 256u;
-		if (mine && my == 0 && !lose)
-			for (uint32_t i = 0; i < cnt; i++)
-				if (s_st[i] != 2 && s_key[i] < key && windows_conflict(s_win[i], w)) {
-					if (s_st[i] == 1) lose = true; else blocked = true;
-				}
+	if (!__syncthreads_or(mine && my == 0)) return;
+	const uint32_t t0 = blockIdx.y * 256u;
+	if (t0 + threadIdx.x < n) {
+		s_key[threadIdx.x] = bb.ckey[t0 + threadIdx.x]; s_win[threadIdx.x] = bb.cwin[t0 + threadIdx.x];
+		s_st[threadIdx.x] = round ? st_in[t0 + threadIdx.x] : (uint8_t)0;
 	}
-	if (!mine) return;
-	const uint8_t now = my ? my : (lose ? (uint8_t)2 : (blocked ? (uint8_t)0 : (uint8_t)1));
+	__syncthreads();
+	if (!mine || my != 0) return;
+	const uint64_t key = bb.ckey[a];
+	const uint4 w = bb.cwin[a];
+	const uint32_t cnt = (n - t0) < 256u ? (n - t0) : 256u;
+	uint32_t f = 0;
+	for (uint32_t i = 0; i < cnt; i++)
+		if (s_st[i] != 2 && s_key[i] < key && windows_conflict(s_win[i], w)) f |= s_st[i] == 1 ? 1u : 2u;
+	if (f) atomicOr(&bb.cflags[a], f);
+}
+/* second half: the verdicts of the round; the taken ones write their journals into the slab at once */
+__global__ void __launch_bounds__(256) k_bulk_round(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab, uint32_t K, uint32_t round)
+{
+	const uint32_t n = (uint32_t)bb.hdr[0];
+	const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= n) return;
+	const uint8_t* st_in = bb.cstate + (size_t)(round & 1u) * K;
+	uint8_t* st_out = bb.cstate + (size_t)((round + 1u) & 1u) * K;
+	const uint8_t my = round ? st_in[a] : (uint8_t)0;
+	const uint32_t f = bb.cflags[a];
+	bb.cflags[a] = 0;
+	const uint8_t now = my ? my : ((f & 1u) ? (uint8_t)2 : ((f & 2u) ? (uint8_t)0 : (uint8_t)1));
 	st_out[a] = now;
 	if (my != 0 || now != 1) return;
+	const uint64_t key = bb.ckey[a];
 	const uint32_t j = (uint32_t)(key & 0xFFFFFu);
 	const unsigned long long at = atomicAdd(&bb.hdr[1], 1ull);
 	bb.taken[at] = j;

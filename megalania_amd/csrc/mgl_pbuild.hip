@@ -35,6 +35,10 @@ struct PBuild {
 	uint32_t nblk, shift;
 	uint16_t* exits;    /* nblk x MGL_PB_ENTRIES: offset past the block end a walk entering at offset e leaves at */
 	uint32_t* entry;    /* nblk + 1: first on-walk position >= blk << shift */
+	uint16_t* gexits;   /* ngrp x MGL_PB_ENTRIES: the exit maps of MGL_PB_GROUP consecutive blocks composed */
+	uint16_t* gentry;   /* ngrp: the entry offset of every group's first block */
+	uint32_t* gsum;     /* ceil(nblk / MGL_PB_OFF_ROWS) x ck_elems: pb_offsets' per-group sums, then their exclusive scan */
+	uint32_t ngrp;
 	uint64_t* tf_ctx;   /* nblk: ctx_state after the block for each of the 12 states before it, 4 bits each */
 	uint32_t* tf_dist;  /* nblk x 8: value[4], source[4] (0..3 = rep distance i before the block, 4 = value) */
 	uint32_t* tf_pk;    /* nblk: packets starting in the block */
@@ -78,6 +82,24 @@ __global__ void __launch_bounds__(320) pb_exits(DevCtx c, Base2 b, PBuild pb)
 	}
 }
 
+/* The chase from block to block is a composition of maps (offset a walk enters a block at -> offset it enters the next one
+ * at), and composition is associative: MGL_PB_GROUP consecutive blocks are composed into one map per group by a workgroup
+ * of its own (one thread per entry offset), one wavefront chases the group maps (n / 2^shift / 64 steps instead of
+ * n / 2^shift: 156 instead of 9 953 at 10 MB), and every group then replays its own blocks from its known entry. */
+#define MGL_PB_GROUP 64u
+__global__ void __launch_bounds__(320) pb_entries_group(PBuild pb)
+{
+	extern __shared__ uint16_t g_rows[]; /* MGL_PB_GROUP x MGL_PB_ENTRIES */
+	const uint32_t g = blockIdx.x, b0 = g * MGL_PB_GROUP;
+	const uint32_t cnt = (pb.nblk - b0) < MGL_PB_GROUP ? (pb.nblk - b0) : MGL_PB_GROUP;
+	for (uint32_t i = threadIdx.x; i < cnt * MGL_PB_ENTRIES; i += blockDim.x) g_rows[i] = pb.exits[(size_t)b0 * MGL_PB_ENTRIES + i];
+	__syncthreads();
+	if (threadIdx.x < MGL_PB_ENTRIES) {
+		uint32_t e = threadIdx.x;
+		for (uint32_t j = 0; j < cnt; j++) e = g_rows[j * MGL_PB_ENTRIES + e];
+		pb.gexits[(size_t)g * MGL_PB_ENTRIES + threadIdx.x] = (uint16_t)e;
+	}
+}
 #define MGL_PB_STAGE 16u
 __global__ void __launch_bounds__(64) pb_entries(DevCtx c, PBuild pb)
 {
@@ -85,13 +107,13 @@ __global__ void __launch_bounds__(64) pb_entries(DevCtx c, PBuild pb)
 	const uint32_t lane = threadIdx.x;
 	if (lane == 0) *pb.rep_free = 0; /* pb_mark, the next kernel, raises it */
 	uint32_t e = 0;
-	for (uint32_t g = 0; g < pb.nblk; g += MGL_PB_STAGE) {
-		const uint32_t cnt = (pb.nblk - g) < MGL_PB_STAGE ? (pb.nblk - g) : MGL_PB_STAGE;
-		for (uint32_t i = lane; i < cnt * MGL_PB_ENTRIES; i += 64) rows[i] = pb.exits[(size_t)g * MGL_PB_ENTRIES + i];
+	for (uint32_t g = 0; g < pb.ngrp; g += MGL_PB_STAGE) {
+		const uint32_t cnt = (pb.ngrp - g) < MGL_PB_STAGE ? (pb.ngrp - g) : MGL_PB_STAGE;
+		for (uint32_t i = lane; i < cnt * MGL_PB_ENTRIES; i += 64) rows[i] = pb.gexits[(size_t)g * MGL_PB_ENTRIES + i];
 		wave_sync();
 		if (lane == 0) {
 			for (uint32_t j = 0; j < cnt; j++) {
-				pb.entry[g + j] = ((g + j) << pb.shift) + e;
+				pb.gentry[g + j] = (uint16_t)e;
 				e = rows[j * MGL_PB_ENTRIES + e];
 			}
 		}
@@ -99,6 +121,17 @@ __global__ void __launch_bounds__(64) pb_entries(DevCtx c, PBuild pb)
 		wave_sync();
 	}
 	if (lane == 0) pb.entry[pb.nblk] = c.n;
+}
+__global__ void __launch_bounds__(64) pb_entries_fill(PBuild pb)
+{
+	const uint32_t g = blockIdx.x, b0 = g * MGL_PB_GROUP;
+	const uint32_t cnt = (pb.nblk - b0) < MGL_PB_GROUP ? (pb.nblk - b0) : MGL_PB_GROUP;
+	if (threadIdx.x != 0) return;
+	uint32_t e = pb.gentry[g];
+	for (uint32_t j = 0; j < cnt; j++) {
+		pb.entry[b0 + j] = ((b0 + j) << pb.shift) + e;
+		e = pb.exits[(size_t)(b0 + j) * MGL_PB_ENTRIES + e];
+	}
 }
 
 /* ctx_state automaton (lzma_state.c:29-57) as one nibble per source state */
@@ -320,24 +353,48 @@ __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 	}
 }
 
-/* per context: counts per block -> offset of the block's first event in the context's chain */
+/* per context: counts per block -> offset of the block's first event in the context's chain.  A column scan over all
+ * blocks per context is 2 616 threads walking 10⁴ rows each (0.6 ms at 10 MB): done in groups of MGL_PB_OFF_ROWS rows
+ * instead -- sums per (context, group), a short scan over the groups, then every group rescans its own rows. */
+#define MGL_PB_OFF_ROWS 128u
+__global__ void __launch_bounds__(256) pb_offsets_sum(Base2 b, PBuild pb)
+{
+	const uint32_t ctx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ctx >= b.ck_elems) return;
+	const uint32_t r0 = blockIdx.y * MGL_PB_OFF_ROWS, r1 = (r0 + MGL_PB_OFF_ROWS) < pb.nblk ? (r0 + MGL_PB_OFF_ROWS) : pb.nblk;
+	const uint32_t* col = pb.hist + ctx;
+	const size_t E = b.ck_elems;
+	uint32_t sum = 0;
+	for (uint32_t blk = r0; blk < r1; blk++) sum += col[(size_t)blk * E];
+	pb.gsum[(size_t)blockIdx.y * E + ctx] = sum;
+}
+__global__ void __launch_bounds__(256) pb_offsets_top(Base2 b, PBuild pb, uint32_t total, uint32_t ngroups)
+{
+	const uint32_t ctx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ctx >= b.ck_elems) return;
+	const size_t E = b.ck_elems;
+	uint32_t run = 0;
+	for (uint32_t g = 0; g < ngroups; g++) { const uint32_t t = pb.gsum[(size_t)g * E + ctx]; pb.gsum[(size_t)g * E + ctx] = run; run += t; }
+	if (ctx < total) b.ch_len[ctx] = run;
+}
 __global__ void __launch_bounds__(256) pb_offsets(Base2 b, PBuild pb, uint32_t total)
 {
 	const uint32_t ctx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (ctx >= b.ck_elems) return;
-	uint32_t run = 0;
-	uint32_t* col = pb.hist + ctx;
+	const uint32_t r0 = blockIdx.y * MGL_PB_OFF_ROWS, r1 = (r0 + MGL_PB_OFF_ROWS) < pb.nblk ? (r0 + MGL_PB_OFF_ROWS) : pb.nblk;
 	const size_t E = b.ck_elems;
-	uint32_t blk = 0;
-	for (; blk + 8 <= pb.nblk; blk += 8) {
+	uint32_t run = pb.gsum[(size_t)blockIdx.y * E + ctx];
+	uint32_t* col = pb.hist + ctx;
+	uint32_t blk = r0;
+	for (; blk + 8 <= r1; blk += 8) {
 		uint32_t t[8];
 #pragma unroll
 		for (int u = 0; u < 8; u++) t[u] = col[(size_t)(blk + u) * E];
 #pragma unroll
 		for (int u = 0; u < 8; u++) { col[(size_t)(blk + u) * E] = run; run += t[u]; }
 	}
-	for (; blk < pb.nblk; blk++) { const uint32_t t = col[(size_t)blk * E]; col[(size_t)blk * E] = run; run += t; }
-	if (ctx < total) b.ch_len[ctx] = run;
+	for (; blk < r1; blk++) { const uint32_t t = col[(size_t)blk * E]; col[(size_t)blk * E] = run; run += t; }
+	(void)total;
 }
 
 /* chain offsets; capacity = 2 len + 257 rounded up to 8 entries, as in k_build */
@@ -482,26 +539,31 @@ __global__ void __launch_bounds__(64) pb_ckpt(DevCtx c, Base2 b)
 		const uint32_t off = b.ch_off[ctx], len = b.ch_len[ctx];
 		const uint32_t* cp = b.ch_pos + off;
 		const uint16_t* ce = b.ch_ev + off;
-		uint32_t lo = 0, hi = len; /* first entry with position >= 64 k0 (len = the sentinel) */
-		const uint32_t want = k0 << MGL_CK2_SHIFT;
-		while (lo < hi) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if (cp[mid] < want) lo = mid + 1; else hi = mid;
-		}
-		uint32_t idx = lo, pos = cp[idx];
+		/* first entry with position >= 64 k0 (len = the sentinel): 8-ary steps, seven probes per round trip */
+		uint32_t idx = chain_lower_bound(cp, len, k0 << MGL_CK2_SHIFT);
+		uint32_t pos = cp[idx];
+		uint16_t val = ce[idx] & 0x7FFFu; /* re-read only when the entry changes: most contexts keep one entry for all 64 rows */
 		for (uint32_t k = k0; k < k1; k++) {
 			const uint32_t at = k << MGL_CK2_SHIFT;
-			if (pos < at) {
-				/* positions in a chain are strictly increasing and pos >= at - 64: the entry wanted is
-				 * at most 64 further on (or the sentinel) */
-				uint32_t a = idx + 1, z = (idx + (1u << MGL_CK2_SHIFT)) < len ? (idx + (1u << MGL_CK2_SHIFT)) : len;
-				while (a < z) {
-					const uint32_t mid = (a + z) >> 1;
-					if (cp[mid] < at) a = mid + 1; else z = mid;
-				}
-				idx = a; pos = cp[idx];
+			/* positions in a chain are strictly increasing and pos >= at - 64: the entry wanted is at most 64 further on
+			 * (or the sentinel, whose position is MGL_POS_INF).  Eight entries per round trip instead of a six-step binary
+			 * search: the busiest contexts have about nine entries per row, most have none (chains are 32-byte aligned
+			 * and over-allocated past their sentinel, like everywhere else) */
+			while (pos < at) {
+				const uint32_t base = idx + 1u; /* entries base .. base + 7, clamped to the sentinel (never below `at`) */
+				uint32_t v[8];
+#pragma unroll
+				for (uint32_t e = 0; e < 8; e++) v[e] = cp[base + e < len ? base + e : len];
+				uint32_t below = 0; /* the entries below `at` are a prefix */
+#pragma unroll
+				for (uint32_t e = 0; e < 8; e++) below += v[e] < at ? 1u : 0u;
+				if (below == 8u) { idx = base + 7u; pos = v[7]; continue; } /* all eight: carry on from the last of them */
+				idx = base + below;
+#pragma unroll
+				for (uint32_t e = 0; e < 8; e++) if (e == below) pos = v[e];
+				val = ce[idx] & 0x7FFFu;
 			}
-			tile[(k - k0) * 64 + lane] = ce[idx] & 0x7FFFu;
+			tile[(k - k0) * 64 + lane] = val;
 		}
 	} else {
 		for (uint32_t k = k0; k < k1; k++) tile[(k - k0) * 64 + lane] = MGL_PROB_INIT;

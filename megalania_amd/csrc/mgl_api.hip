@@ -269,7 +269,12 @@ static int launch_pbuild(mgl_sa* sa)
 	hipLaunchKernelGGL(pb_entries, dim3(1), dim3(64), 0, st, c, pb);
 	hipLaunchKernelGGL(pb_entries_fill, dim3(pb.ngrp), dim3(64), 0, st, pb);
 	hipLaunchKernelGGL(pb_mark, dim3((pb.nblk + 63) / 64), dim3(64), 0, st, c, b, pb, ctl);
-	hipLaunchKernelGGL(pb_scan, dim3(1), dim3(64), 0, st, pb);
+	{
+		const uint32_t nch = (pb.nblk + MGL_PB_SCAN_CHUNK - 1u) / MGL_PB_SCAN_CHUNK;
+		hipLaunchKernelGGL(pb_scan_chunks, dim3((nch + 255u) / 256u), dim3(256), 0, st, pb);
+		hipLaunchKernelGGL(pb_scan, dim3(1), dim3(64), 0, st, pb);
+		hipLaunchKernelGGL(pb_scan_fill, dim3((nch + 255u) / 256u), dim3(256), 0, st, pb);
+	}
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
 	hipLaunchKernelGGL(pb_walk<false>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
@@ -533,7 +538,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_aos); dfree(sa->d_cum); dfree(sa->d_final_probs);
 	free_b2(sa->b2, false);
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
-	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.gexits); dfree(sa->pb.gentry); dfree(sa->pb.gsum); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
+	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.gexits); dfree(sa->pb.gentry); dfree(sa->pb.gsum); dfree(sa->pb.ch_map); dfree(sa->pb.ch_vs); dfree(sa->pb.ch_pk); dfree(sa->pb.ch_state); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
 	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.rep_free); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	{
 		mgl_sa::NbrSet& t = sa->alt;
@@ -767,6 +772,13 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			pb.ngrp = (pb.nblk + MGL_PB_GROUP - 1u) / MGL_PB_GROUP;
 			HIPCHK(hipMalloc(&pb.gexits, sizeof(uint16_t) * (size_t)pb.ngrp * MGL_PB_ENTRIES));
 			HIPCHK(hipMalloc(&pb.gentry, sizeof(uint16_t) * (size_t)pb.ngrp));
+			{
+				const size_t nch = ((size_t)pb.nblk + MGL_PB_SCAN_CHUNK - 1u) / MGL_PB_SCAN_CHUNK;
+				HIPCHK(hipMalloc(&pb.ch_map, sizeof(uint64_t) * nch));
+				HIPCHK(hipMalloc(&pb.ch_vs, sizeof(uint32_t) * 8 * nch));
+				HIPCHK(hipMalloc(&pb.ch_pk, sizeof(uint32_t) * nch));
+				HIPCHK(hipMalloc(&pb.ch_state, sizeof(uint32_t) * 8 * nch));
+			}
 			HIPCHK(hipMalloc(&pb.gsum, sizeof(uint32_t) * (size_t)((pb.nblk + MGL_PB_OFF_ROWS - 1u) / MGL_PB_OFF_ROWS) * ckpt_elems));
 			HIPCHK(hipMalloc(&pb.tf_ctx, sizeof(uint64_t) * pb.nblk));
 			HIPCHK(hipMalloc(&pb.tf_dist, sizeof(uint32_t) * 8 * (size_t)pb.nblk));

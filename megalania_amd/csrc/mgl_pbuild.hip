@@ -38,6 +38,10 @@ struct PBuild {
 	uint16_t* gexits;   /* ngrp x MGL_PB_ENTRIES: the exit maps of MGL_PB_GROUP consecutive blocks composed */
 	uint16_t* gentry;   /* ngrp: the entry offset of every group's first block */
 	uint32_t* gsum;     /* ceil(nblk / MGL_PB_OFF_ROWS) x ck_elems: pb_offsets' per-group sums, then their exclusive scan */
+	uint64_t* ch_map;   /* per chunk of MGL_PB_SCAN_CHUNK blocks: their transforms composed (pb_scan_chunks) ... */
+	uint32_t* ch_vs;    /* ... values[4], sources[4] ... */
+	uint32_t* ch_pk;    /* ... packets */
+	uint32_t* ch_state; /* per chunk x 8: the walk state its first block starts in (pb_scan) */
 	uint32_t ngrp;
 	uint64_t* tf_ctx;   /* nblk: ctx_state after the block for each of the 12 states before it, 4 bits each */
 	uint32_t* tf_dist;  /* nblk x 8: value[4], source[4] (0..3 = rep distance i before the block, 4 = value) */
@@ -244,38 +248,77 @@ __device__ __forceinline__ void pb_tf_then(PbTf& a, const PbTf& t)
 	a.v0 = nv0; a.v1 = nv1; a.v2 = nv2; a.v3 = nv3; a.s0 = ns0; a.s1 = ns1; a.s2 = ns2; a.s3 = ns3;
 }
 
-/* 4096 blocks per round: every lane composes its 64 consecutive blocks, the 64 lane totals are
- * applied in order (uniform), then every lane replays its blocks from its own entry state */
+__device__ __forceinline__ PbTf pb_tf_shfl_up(const PbTf& a, int o)
+{
+	PbTf t;
+	t.map = shfl_up64(a.map, o);
+	t.v0 = (uint32_t)__shfl_up((int)a.v0, o, 64); t.v1 = (uint32_t)__shfl_up((int)a.v1, o, 64);
+	t.v2 = (uint32_t)__shfl_up((int)a.v2, o, 64); t.v3 = (uint32_t)__shfl_up((int)a.v3, o, 64);
+	t.s0 = (uint32_t)__shfl_up((int)a.s0, o, 64); t.s1 = (uint32_t)__shfl_up((int)a.s1, o, 64);
+	t.s2 = (uint32_t)__shfl_up((int)a.s2, o, 64); t.s3 = (uint32_t)__shfl_up((int)a.s3, o, 64);
+	return t;
+}
+/* The walk state every block starts in: the blocks' transforms composed in order.  Three kernels: every thread composes
+ * MGL_PB_SCAN_CHUNK consecutive blocks into one transform (wide), one wavefront applies the chunk transforms in order, 64
+ * per trip (n / 2^shift / 8 steps of register work: 1 244 at 10 MB), every thread replays its chunk from its own entry
+ * state (wide).  (One wavefront doing all three with 64 blocks per lane took 0.38 ms at 10 MB.) */
+#define MGL_PB_SCAN_CHUNK 8u
+__global__ void __launch_bounds__(256) pb_scan_chunks(PBuild pb)
+{
+	const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t first = ch * MGL_PB_SCAN_CHUNK;
+	if (first >= pb.nblk) return;
+	const uint32_t last = (first + MGL_PB_SCAN_CHUNK) < pb.nblk ? (first + MGL_PB_SCAN_CHUNK) : pb.nblk;
+	PbTf acc;
+	acc.map = MGL_PB_MAP_ID; acc.v0 = acc.v1 = acc.v2 = acc.v3 = 0; acc.s0 = 0; acc.s1 = 1; acc.s2 = 2; acc.s3 = 3;
+	uint32_t packets = 0;
+	for (uint32_t blk = first; blk < last; blk++) {
+		const PbTf t = pb_tf_load(pb, blk);
+		pb_tf_then(acc, t);
+		packets += pb.tf_pk[blk];
+	}
+	pb.ch_map[ch] = acc.map;
+	((uint4*)pb.ch_vs)[(size_t)ch * 2] = make_uint4(acc.v0, acc.v1, acc.v2, acc.v3);
+	((uint4*)pb.ch_vs)[(size_t)ch * 2 + 1] = make_uint4(acc.s0, acc.s1, acc.s2, acc.s3);
+	pb.ch_pk[ch] = packets;
+}
 __global__ void __launch_bounds__(64) pb_scan(PBuild pb)
 {
 	const uint32_t lane = threadIdx.x;
+	const uint32_t nch = (pb.nblk + MGL_PB_SCAN_CHUNK - 1u) / MGL_PB_SCAN_CHUNK;
 	uint32_t cs = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0; /* uniform running state */
 	unsigned long long packets = 0;
-	for (uint32_t g = 0; g < pb.nblk; g += 4096) {
-		const uint32_t first = g + lane * 64u;
-		const uint32_t last = (first + 64u) < pb.nblk ? (first + 64u) : pb.nblk;
+	for (uint32_t g = 0; g < nch; g += 64) {
+		const uint32_t ch = g + lane;
 		PbTf acc;
 		acc.map = MGL_PB_MAP_ID; acc.v0 = acc.v1 = acc.v2 = acc.v3 = 0; acc.s0 = 0; acc.s1 = 1; acc.s2 = 2; acc.s3 = 3;
-		for (uint32_t blk = first; blk < last; blk++) {
-			const PbTf t = pb_tf_load(pb, blk);
-			pb_tf_then(acc, t);
-			packets += pb.tf_pk[blk];
+		if (ch < nch) {
+			acc.map = pb.ch_map[ch];
+			const uint4 tv = ((const uint4*)pb.ch_vs)[(size_t)ch * 2], ts = ((const uint4*)pb.ch_vs)[(size_t)ch * 2 + 1];
+			acc.v0 = tv.x; acc.v1 = tv.y; acc.v2 = tv.z; acc.v3 = tv.w; acc.s0 = ts.x; acc.s1 = ts.y; acc.s2 = ts.z; acc.s3 = ts.w;
+			packets += pb.ch_pk[ch];
 		}
-		uint32_t my_cs = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-		for (uint32_t j = 0; j < 64; j++) {
-			if (lane == j) { my_cs = cs; m0 = d0; m1 = d1; m2 = d2; m3 = d3; }
-			PbTf t;
-			t.map = rdlane64(acc.map, j);
-			t.v0 = rdlane(acc.v0, j); t.v1 = rdlane(acc.v1, j); t.v2 = rdlane(acc.v2, j); t.v3 = rdlane(acc.v3, j);
-			t.s0 = rdlane(acc.s0, j); t.s1 = rdlane(acc.s1, j); t.s2 = rdlane(acc.s2, j); t.s3 = rdlane(acc.s3, j);
-			pb_tf_apply(t, cs, d0, d1, d2, d3);
+		/* composition is associative: an inclusive scan over the lanes (six shuffle-and-compose steps) instead of 64
+		 * transforms applied one after the other */
+		for (int o = 1; o < 64; o <<= 1) {
+			PbTf t = pb_tf_shfl_up(acc, o);
+			if ((int)lane >= o) { pb_tf_then(t, acc); acc = t; } /* (lanes lane-2o+1 .. lane-o) then (lane-o+1 .. lane) */
 		}
-		for (uint32_t blk = first; blk < last; blk++) {
-			uint4* o = (uint4*)(pb.st_in + (size_t)blk * 8);
-			o[0] = make_uint4(my_cs, m0, m1, m2);
-			o[1] = make_uint4(m3, 0, 0, 0);
-			const PbTf t = pb_tf_load(pb, blk);
-			pb_tf_apply(t, my_cs, m0, m1, m2, m3);
+		/* this lane's chunk starts in the running state put through the chunks before it in this trip */
+		PbTf ex = pb_tf_shfl_up(acc, 1);
+		uint32_t my_cs = cs, m0 = d0, m1 = d1, m2 = d2, m3 = d3;
+		if (lane != 0) pb_tf_apply(ex, my_cs, m0, m1, m2, m3);
+		/* and the running state moves on through all 64 */
+		{
+			PbTf all;
+			all.map = rdlane64(acc.map, 63);
+			all.v0 = rdlane(acc.v0, 63); all.v1 = rdlane(acc.v1, 63); all.v2 = rdlane(acc.v2, 63); all.v3 = rdlane(acc.v3, 63);
+			all.s0 = rdlane(acc.s0, 63); all.s1 = rdlane(acc.s1, 63); all.s2 = rdlane(acc.s2, 63); all.s3 = rdlane(acc.s3, 63);
+			pb_tf_apply(all, cs, d0, d1, d2, d3);
+		}
+		if (ch < nch) {
+			((uint4*)pb.ch_state)[(size_t)ch * 2] = make_uint4(my_cs, m0, m1, m2);
+			((uint4*)pb.ch_state)[(size_t)ch * 2 + 1] = make_uint4(m3, 0, 0, 0);
 		}
 	}
 	packets = wave_sum64(packets);
@@ -283,6 +326,22 @@ __global__ void __launch_bounds__(64) pb_scan(PBuild pb)
 		pb.acc[0] = 0;
 		pb.acc[1] = packets;
 		pb.acc[2] = cs; pb.acc[3] = d0; pb.acc[4] = d1; pb.acc[5] = d2; pb.acc[6] = d3; pb.acc[7] = 0;
+	}
+}
+__global__ void __launch_bounds__(256) pb_scan_fill(PBuild pb)
+{
+	const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t first = ch * MGL_PB_SCAN_CHUNK;
+	if (first >= pb.nblk) return;
+	const uint32_t last = (first + MGL_PB_SCAN_CHUNK) < pb.nblk ? (first + MGL_PB_SCAN_CHUNK) : pb.nblk;
+	const uint4 s0 = ((const uint4*)pb.ch_state)[(size_t)ch * 2], s1 = ((const uint4*)pb.ch_state)[(size_t)ch * 2 + 1];
+	uint32_t my_cs = s0.x, m0 = s0.y, m1 = s0.z, m2 = s0.w, m3 = s1.x;
+	for (uint32_t blk = first; blk < last; blk++) {
+		uint4* o = (uint4*)(pb.st_in + (size_t)blk * 8);
+		o[0] = make_uint4(my_cs, m0, m1, m2);
+		o[1] = make_uint4(m3, 0, 0, 0);
+		const PbTf t = pb_tf_load(pb, blk);
+		pb_tf_apply(t, my_cs, m0, m1, m2, m3);
 	}
 }
 

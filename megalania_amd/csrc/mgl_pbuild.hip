@@ -378,6 +378,47 @@ __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 	while (w.st.pos < end) {
 		const uint32_t pos = w.st.pos;
 		walk_window(w, c, b.slab, lane);
+		if (w.st.ctx_state < 7u) {
+			/* a run of plain literals: up to seven are planned at once, nine lanes each (is_match + the eight tree nodes);
+			 * their events take their chain slots packet by packet, because the packets share contexts (is_match, the top
+			 * of the literal tree) and a chain is in position order -- the model replay of mgl_kernels2.hip does the same */
+			const uint32_t o = pos - w.wbase;
+			uint32_t lt, ld, ll;
+			const uint32_t myp = w.wbase + lane;
+			pb_decode(w.wpk, myp, c.n, lt, ld, ll);
+			const unsigned long long lit = __ballot(myp < c.n && lt == MGL_LITERAL) >> o;
+			uint32_t run = ~lit == 0ull ? 64u : (uint32_t)__ffsll((long long)~lit) - 1u;
+			run = run < 64u - o ? run : 64u - o;
+			run = run < end - pos ? run : end - pos;
+			if (run >= 2u) {
+				const uint32_t take = run < 7u ? run : 7u;
+				const uint32_t i = lane / 9u, slot = lane - i * 9u, p = pos + i;
+				const bool active = i < take;
+				const uint32_t byte = (uint32_t)__shfl((int)w.wbyte, (int)((p - w.wbase) & 63u), 64);
+				uint32_t prev_byte = 0;
+				if (c.L.lc > 0) {
+					const uint32_t wprev = (uint32_t)__shfl((int)w.wbyte, (int)((p - 1u - w.wbase) & 63u), 64);
+					prev_byte = p == 0 ? 0u : (p - 1u >= w.wbase ? wprev : (uint32_t)c.data[p - 1u]);
+				}
+				mgl_wstate sv = w.st;
+				sv.pos = p; sv.ctx_state = lit_steps(w.st.ctx_state, i);
+				mgl_plan pl;
+				mgl_plan_packet(&c.L, &sv, MGL_LITERAL, 0, 1, byte, 0, prev_byte, &pl);
+				if (!__ballot(active && pl.nev != 9u)) {
+					uint32_t ctx = 0, bit = 0;
+					if (active) mgl_plan_event(&pl, slot, &ctx, &bit);
+					for (uint32_t r = 0; r < take; r++) {
+						if (active && i == r) {
+							const uint32_t k = cnt[ctx]++;
+							if (SCATTER) { b.ch_pos[k] = p; b.ch_ev[k] = (uint16_t)(bit << 15); }
+						}
+						wave_sync();
+					}
+					w.st.pos += take; w.st.ctx_state = lit_steps(w.st.ctx_state, take);
+					continue;
+				}
+			}
+		}
 		uint32_t type, dist, len;
 		pb_decode(walk_slab_at(w, pos), pos, c.n, type, dist, len);
 		if (!SCATTER && type != MGL_LITERAL && lane < 8) {

@@ -226,14 +226,18 @@ def test_epoch_snapshots_equal_rebuild(name, K, golden, golden_input):
     b.close()
 
 
-@pytest.mark.parametrize("cfg,size,K,steps", [("c2", 100000, 1024, 40), ("c5", 70000, 256, 30), ("c2", 5000, 64, 60), ("c2", 1025, 32, 20)])
-def test_parallel_build_equals_serial_build(cfg, size, K, steps):
+@pytest.mark.parametrize("cfg,size,K,steps,accept", [("c2", 100000, 1024, 40, "single"), ("c5", 70000, 256, 30, "single"), ("c2", 5000, 64, 60, "single"),
+                                                     ("c2", 1025, 32, 20, "single"), ("c2", 16384, 64, 20, "single"), ("c2", 16385, 64, 20, "single"),
+                                                     ("c2", 300001, 2048, 6, "bulk")])
+def test_parallel_build_equals_serial_build(cfg, size, K, steps, accept):
     """mgl_pbuild.hip (block-parallel) and k_build (one wavefront) derive identical structures,
     totals and final walk state -- all-literal and SA-evolved slabs, pb = 0 and 2, sizes that end
-    inside a block and one byte into a new one."""
+    inside a block and one byte into a new one, block counts at and one past a group of 64 (the grouped entry
+    chase), and 1 172 blocks = 19 groups / 147 chunks / 10 row groups (more than one trip of every staged loop),
+    there on a slab thousands of bulk-step moves away from the literal one."""
     data, _ = corpus.config_input(cfg, size)
     props = dict(pb=2, max_bucket_scan=512) if cfg == "c5" else {}
-    par = binding.SA(data, accept="single", neighbours_per_step=K, seed=3, **props)
+    par = binding.SA(data, accept=accept, neighbours_per_step=K, seed=3, **props)
     ser = binding.SA(data, accept="single", neighbours_per_step=8, seed=3, serial_build=True, snapshots=False, **props)
     o = Oracle(data, dict_limit=0x400000, **({"pb": 2} if cfg == "c5" else {}))
     for round_ in range(2):

@@ -1084,6 +1084,10 @@ static int parse_is_valid(const orc_ctx* c, const orc_packet* slab)
 
 /* Two neighbours (window = target, end, soft_end, dep) cannot both be taken: with A the one that starts first,
  * unless B starts at or after A's soft end, and either B is self-contained or B starts at or after A's end. */
+/* bulk steps of orc_sa_batched whose combined parse failed the check and was taken back (tests: the window rule should never need this net) */
+static uint64_t g_bulk_rollbacks;
+uint64_t orc_bulk_rollbacks(void) { return g_bulk_rollbacks; }
+
 static int windows_conflict(const uint32_t* x, const uint32_t* y)
 {
 	const uint32_t* a = x[0] <= y[0] ? x : y;
@@ -1202,6 +1206,7 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 				for (size_t e = 0; e < nd[j]; e++) slab[diffs[(size_t)j * ORC_MAX_JOURNAL + e].position] = diffs[(size_t)j * ORC_MAX_JOURNAL + e].old_packet;
 			}
 			ntaken = 0;
+			g_bulk_rollbacks++;
 		}
 		if (ntaken) {
 			cur = (!bulk) ? costs[minj] : orc_cost_slab(c, slab, NULL, NULL, NULL, NULL, NULL);

@@ -104,6 +104,8 @@ class Oracle:
             L.orc_sa_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.c_uint32, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.orc_bulk_rollbacks.restype = C.c_uint64
+            L.orc_bulk_rollbacks.argtypes = []
             L.orc_neighbour_ex.restype = C.c_int
             L.orc_neighbour_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -222,6 +224,10 @@ class Oracle:
                               C.addressof(dropped))
         return dict(cur=cur_c.value, best=best_c.value, trace=trace.reshape(-1, 4).copy(), valid=valid.value,
                     dropped=dropped.value)
+
+    def bulk_rollbacks(self) -> int:
+        """bulk steps the oracle took back since the library was loaded (a process-wide counter)"""
+        return int(self.L.orc_bulk_rollbacks())
 
     def emit(self, slab) -> bytes:
         cap = 2 * self.n + 1024

@@ -141,3 +141,32 @@ def test_batched_semantics_selfconsistent():
             applied[d["position"]] = d["new"]
         assert (applied == kept).all()
         assert lzma.decompress(o.emit(kept), format=lzma.FORMAT_ALONE) == data
+
+
+@pytest.mark.parametrize("name,seed", [("lorem", 1), ("lorem", 2), ("enwik", 3), ("enwik", 4), ("runs", 5), ("runs", 6), ("zeros", 7)])
+def test_bulk_steps_on_the_oracle_never_need_the_rollback(name, seed):
+    """The bulk step's selection rests on a local argument about windows and rep distances; the
+    oracle checks every combined parse and takes a failing step back as a whole.  On repetitive, text-like and run-heavy
+    inputs (rep packets everywhere) that net is never needed, the exact cost the step reports is a full walk's, and the
+    stream decodes -- CPU only, so it runs wherever the tests run."""
+    from megalania_amd import corpus
+    data = {"lorem": corpus.lorem(2200), "enwik": corpus.enwik_like(3000, 0x77 + seed),
+            "runs": b"a" * 300 + b"ab" * 200 + bytes(range(64)) * 3 + b"a" * 120 + b"abcabcabd" * 40,
+            "zeros": bytes(900) + b"\x01\x02" * 50 + bytes(400)}[name]
+    n = len(data)
+    o = Oracle(data)
+    slab, best = literal_slab(n), literal_slab(n)
+    before = o.bulk_rollbacks()
+    K, steps = 48, 36
+    cur = best_cost = 0
+    taken = 0
+    for s0 in range(0, steps, 6):
+        res = o.sa_batched(slab, best, cur, best_cost, seed=seed * 1000003, K=K, phase=0, iters_per_epoch=n,
+                           step_begin=s0, step_end=s0 + 6, iter0=s0 * K, modes=[1] * 6)
+        cur, best_cost = res["cur"], res["best"]
+        taken += int(res["trace"][:, 1].sum())
+        assert cur == o.cost_slab(slab)["total"]
+        assert best_cost == o.cost_slab(best)["total"] <= cur
+        assert lzma.decompress(o.emit(slab), format=lzma.FORMAT_ALONE) == data
+    assert o.bulk_rollbacks() == before
+    assert taken >= 12  # the steps did take moves (several per step on the text-like inputs)

@@ -539,7 +539,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	free_b2(sa->b2, false);
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
 	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.gexits); dfree(sa->pb.gentry); dfree(sa->pb.gsum); dfree(sa->pb.ch_map); dfree(sa->pb.ch_vs); dfree(sa->pb.ch_pk); dfree(sa->pb.ch_state); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
-	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.rep_free); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
+	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	{
 		mgl_sa::NbrSet& t = sa->alt;
 		dfree(t.nbr.cost); dfree(t.nbr.ndiffs); dfree(t.nbr.walked); dfree(t.nbr.win); dfree(t.nbr.win2); dfree(t.nbr.dpos); dfree(t.nbr.dold); dfree(t.nbr.dnew);
@@ -786,8 +786,6 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&pb.st_in, sizeof(uint32_t) * 8 * (size_t)pb.nblk));
 			HIPCHK(hipMalloc(&pb.hist, sizeof(uint32_t) * (size_t)pb.nblk * ckpt_elems));
 			HIPCHK(hipMalloc(&pb.acc, sizeof(unsigned long long) * 8));
-			HIPCHK(hipMalloc(&pb.rep_free, sizeof(uint32_t)));
-			HIPCHK(hipMemset(pb.rep_free, 0, sizeof(uint32_t)));
 			pb.seg_cap = b.pool_cap / MGL_PB_SEG + ckpt_elems + 64u;
 			HIPCHK(hipMalloc(&pb.seg_off, sizeof(uint32_t) * (ckpt_elems + 1)));
 			HIPCHK(hipMalloc(&pb.unres, pb.seg_cap));

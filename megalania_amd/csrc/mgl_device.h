@@ -98,7 +98,6 @@ struct Control {
 	uint32_t taken;          /* neighbours the last step took */
 	uint32_t bulk_was_best;  /* bulk step: the base held the best slab's structures when the step began */
 	uint32_t bulk_need_undo; /* bulk step: the best slab has to be restored from the new one + the undo log */
-	uint32_t rep_free_from;  /* the base parse holds no SHORT_REP / LONG_REP packet at or after this position (0: none at all) */
 	uint32_t la_lo, la_end;  /* window of the move the last step accepted (la_lo = MGL_POS_INF: none) */
 	uint32_t mod_lo, mod_hi; /* the last accepted move changed some context's probability before positions in (mod_lo, mod_hi] (MGL_POS_INF: to the end) */
 };

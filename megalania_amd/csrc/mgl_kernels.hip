@@ -658,8 +658,7 @@ __global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* c
 	uint64_t bits = 0;
 	if (w.st.pos & 63u) bits = b.onwalk[word] & ((1ull << (w.st.pos & 63u)) - 1ull);
 
-	uint32_t guard = 0, rep_from = ci == 0 ? 0u : uni(ctl->rep_free_from); /* a restart keeps what lies before it */
-	if (ci != 0 && rep_from > w.st.pos) rep_from = 0xFFFFFFFFu; /* unknown once the tail is rewalked: re-derived below */
+	uint32_t guard = 0;
 	while (w.st.pos < c.n) {
 		const uint32_t pos = w.st.pos;
 		if (++guard > c.n) { if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); break; }
@@ -683,7 +682,6 @@ __global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* c
 			type = MGL_LITERAL; len = 1; dist = 0;
 			if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
 		}
-		if (type == MGL_SHORT_REP || type == MGL_LONG_REP) rep_from = pos + 1u;
 		walk_packet<true>(w, c, probs, T, type, dist, len, lane);
 		if (cum_out) {
 			uint64_t cum = base_cum + wave_sum64(w.acc);
@@ -700,8 +698,6 @@ __global__ void __launch_bounds__(64) k_rebuild(DevCtx c, BaseView b, Control* c
 	if (final_probs) for (uint32_t i = lane; i < c.L.total; i += 64) final_probs[i] = probs[i];
 	if (lane == 0) {
 		ctl->packets = w.packets;
-		/* a partial rewalk that met no rep packet cannot tell where the rep-free tail starts: 0 only when it is known */
-		ctl->rep_free_from = rep_from == 0xFFFFFFFFu ? c.n : rep_from;
 		ctl->rebuild_cost = total;
 		ctl->final_ctx_state = w.st.ctx_state;
 		ctl->final_dists[0] = w.st.dists[0]; ctl->final_dists[1] = w.st.dists[1];

@@ -52,7 +52,7 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 	Walk w;
 	walk_reset(w);
 	BitAcc on = { 0, 0 }, sp = { 0, 0 };
-	uint32_t guard = 0, rep_from = 0;
+	uint32_t guard = 0;
 	while (w.st.pos < c.n) {
 		const uint32_t pos = w.st.pos;
 		if (++guard > c.n) { if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); break; }
@@ -66,7 +66,6 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 			type = MGL_LITERAL; len = 1; dist = 0;
 			if (lane == 0) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
 		}
-		if (type == MGL_SHORT_REP || type == MGL_LONG_REP) rep_from = pos + 1u;
 		if (type != MGL_LITERAL) {
 			sp.bits |= 1ull << (pos & 63u);
 			if (lane < 8) {
@@ -201,7 +200,6 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 	const uint64_t cost = wave_sum64(w.acc);
 	if (lane == 0) {
 		ctl->packets = npackets;
-		ctl->rep_free_from = rep_from;
 		ctl->rebuild_cost = cost;
 		ctl->final_ctx_state = w.st.ctx_state;
 		ctl->final_dists[0] = w.st.dists[0]; ctl->final_dists[1] = w.st.dists[1];

@@ -253,26 +253,6 @@ __global__ void __launch_bounds__(64) k_apply_walk(DevCtx c, Base2 b, Control* c
 	wave_sync();
 	/* the journal goes into the slab (main.c keeps the mutated slab on accept) */
 	if (lane < nd) b.slab[s_jpos[lane]] = s_jnew[lane];
-	/* where the parse's rep-free tail starts now: behind the last rep packet the journal brought, or, when the old
-	 * last rep packet left the walk, behind the nearest one before it (a walk back over the special packets) */
-	__threadfence();
-	wave_sync();
-	if (lane == 0 && !failed) {
-		uint32_t rf = ctl->rep_free_from;
-		for (uint32_t i = 0; i < nd; i++) {
-			const uint32_t ty = mgl_pk_type(s_jnew[i]);
-			if ((ty == MGL_SHORT_REP || ty == MGL_LONG_REP) && s_jpos[i] + 1u > rf) rf = s_jpos[i] + 1u;
-		}
-		while (rf > 0) {
-			const uint32_t p = rf - 1u;
-			const bool special = (b.sp0[p >> 6] >> (p & 63u)) & 1ull; /* on the walk and not a literal */
-			const uint32_t ty = mgl_pk_type(b.slab[p]);
-			if (special && (ty == MGL_SHORT_REP || ty == MGL_LONG_REP)) break;
-			const uint32_t q = p == 0 ? MGL_POS_INF : sp_find_prev(b, p - 1u);
-			rf = q == MGL_POS_INF ? 0u : q + 1u;
-		}
-		ctl->rep_free_from = rf;
-	}
 	/* touched contexts, ascending */
 	uint32_t nt = 0;
 	for (uint32_t wbase = 0; wbase < 512; wbase += 64) {
@@ -732,7 +712,7 @@ struct SnapPlan {
 	const uint32_t* src_pool_top;
 };
 struct SnapMeta {
-	uint32_t valid, final_ctx_state, rep_free_from, pad;
+	uint32_t valid, final_ctx_state, pad0, pad;
 	uint32_t final_dists[4];
 	unsigned long long packets, cost;
 };
@@ -751,13 +731,11 @@ __global__ void __launch_bounds__(256) k_snapshot(SnapPlan p, Control* ctl, Snap
 			for (int i = 0; i < 4; i++) meta->final_dists[i] = ctl->final_dists[i];
 			meta->packets = ctl->packets;
 			meta->cost = ctl->rebuild_cost;
-			meta->rep_free_from = ctl->rep_free_from;
 		} else {
 			ctl->final_ctx_state = meta->final_ctx_state;
 			for (int i = 0; i < 4; i++) ctl->final_dists[i] = meta->final_dists[i];
 			ctl->packets = meta->packets;
 			ctl->rebuild_cost = meta->cost;
-			ctl->rep_free_from = meta->rep_free_from;
 		}
 	}
 	const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -52,7 +52,6 @@ struct PBuild {
 	uint32_t* seg_off;  /* total + 1: first pb_sim segment of each context */
 	uint8_t* unres;     /* per segment: warm-up did not pin the probability, left to pb_sim_fix */
 	uint32_t seg_cap;
-	uint32_t* rep_free; /* one word: position after the last SHORT_REP / LONG_REP packet of the parse (0: none) */
 	uint32_t force_fix; /* diagnostic: treat every warm-up as inconclusive (exercises pb_sim_fix) */
 };
 
@@ -109,7 +108,6 @@ __global__ void __launch_bounds__(64) pb_entries(DevCtx c, PBuild pb)
 {
 	__shared__ uint16_t rows[MGL_PB_STAGE * MGL_PB_ENTRIES];
 	const uint32_t lane = threadIdx.x;
-	if (lane == 0) *pb.rep_free = 0; /* pb_mark, the next kernel, raises it */
 	uint32_t e = 0;
 	for (uint32_t g = 0; g < pb.ngrp; g += MGL_PB_STAGE) {
 		const uint32_t cnt = (pb.ngrp - g) < MGL_PB_STAGE ? (pb.ngrp - g) : MGL_PB_STAGE;
@@ -155,7 +153,7 @@ __global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Cont
 	uint32_t word = w_first;
 	uint64_t on = 0, sp = 0;
 	uint64_t map = MGL_PB_MAP_ID;
-	uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, s0 = 0, s1 = 1, s2 = 2, s3 = 3, npk = 0, rep_from = 0;
+	uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, s0 = 0, s1 = 1, s2 = 2, s3 = 3, npk = 0;
 	bool bad = false;
 	while (p < end) {
 		const uint32_t w = p >> 6;
@@ -172,7 +170,6 @@ __global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Cont
 		if (type != MGL_LITERAL) {
 			sp |= bit;
 			tbl = type == MGL_MATCH ? MGL_PB_MAP_MATCH : type == MGL_SHORT_REP ? MGL_PB_MAP_SREP : MGL_PB_MAP_LREP;
-			if (type != MGL_MATCH) rep_from = p + 1u;
 			if (type == MGL_MATCH) {
 				v3 = v2; s3 = s2; v2 = v1; s2 = s1; v1 = v0; s1 = s0;
 				v0 = dist; s0 = 4;
@@ -203,7 +200,6 @@ __global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Cont
 	uint32_t* t = pb.tf_dist + (size_t)blk * 8;
 	t[0] = v0; t[1] = v1; t[2] = v2; t[3] = v3; t[4] = s0; t[5] = s1; t[6] = s2; t[7] = s3;
 	pb.tf_pk[blk] = npk;
-	if (rep_from) atomicMax(pb.rep_free, rep_from);
 	if (bad) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN);
 }
 
@@ -677,7 +673,6 @@ __global__ void pb_finish(PBuild pb, Control* ctl)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	ctl->packets = pb.acc[1];
-	ctl->rep_free_from = *pb.rep_free;
 	ctl->rebuild_cost = pb.acc[0];
 	ctl->final_ctx_state = (uint32_t)pb.acc[2];
 	for (int i = 0; i < 4; i++) ctl->final_dists[i] = (uint32_t)pb.acc[3 + i];

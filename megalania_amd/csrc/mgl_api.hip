@@ -268,7 +268,7 @@ static int launch_pbuild(mgl_sa* sa)
 	hipLaunchKernelGGL(pb_entries_group, dim3(pb.ngrp), dim3(320), MGL_PB_GROUP * MGL_PB_ENTRIES * 2u, st, pb);
 	hipLaunchKernelGGL(pb_entries, dim3(1), dim3(64), 0, st, c, pb);
 	hipLaunchKernelGGL(pb_entries_fill, dim3(pb.ngrp), dim3(64), 0, st, pb);
-	hipLaunchKernelGGL(pb_mark, dim3((pb.nblk + 63) / 64), dim3(64), 0, st, c, b, pb, ctl);
+	hipLaunchKernelGGL(pb_mark, dim3(pb.nblk), dim3(64), 0, st, c, b, pb, ctl);
 	{
 		const uint32_t nch = (pb.nblk + MGL_PB_SCAN_CHUNK - 1u) / MGL_PB_SCAN_CHUNK;
 		hipLaunchKernelGGL(pb_scan_chunks, dim3((nch + 255u) / 256u), dim3(256), 0, st, pb);

@@ -143,9 +143,10 @@ __global__ void __launch_bounds__(64) pb_entries_fill(PBuild pb)
 #define MGL_PB_MAP_SREP 0x0000BBBBB9999999ull
 #define MGL_PB_MAP_LREP 0x0000BBBBB8888888ull
 
-/* One wavefront per block: the block's slab entries come into LDS with coalesced loads, then lane 0 follows the packets from
- * the block's entry position there (a thread per block chasing them through global memory waited a full memory round trip
- * per packet: 0.47 ms at 10 MB). */
+/* One wavefront per block: the block's slab entries come into LDS with coalesced loads, then the wavefront follows the packets
+ * from the block's entry position there, every lane doing the same (uniform) bookkeeping and lanes 0..11 each following the
+ * ctx_state automaton from one source state.  (A thread per block chasing the packets through global memory waited a memory
+ * round trip per packet and composed a 12-nibble map per packet on its own: 0.47 ms at 10 MB.) */
 __global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Control* ctl)
 {
 	__shared__ mgl_pk s_slab[MGL_PB_MAX_BLOCK];
@@ -155,19 +156,23 @@ __global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Cont
 	const uint32_t end = ((blk + 1) << pb.shift) < c.n ? ((blk + 1) << pb.shift) : c.n;
 	for (uint32_t i = threadIdx.x; base + i < end; i += blockDim.x) s_slab[i] = b.slab[base + i];
 	wave_sync();
-	if (threadIdx.x != 0) return;
-	uint32_t p = pb.entry[blk];
+	const uint32_t lane = threadIdx.x;
+	uint32_t p = uni(pb.entry[blk]);
 	const uint32_t w_first = blk << (pb.shift - 6), w_lim = (w_first + (1u << (pb.shift - 6))) < b.nw0 ? (w_first + (1u << (pb.shift - 6))) : b.nw0;
 	uint32_t word = w_first;
 	uint64_t on = 0, sp = 0;
-	uint64_t map = MGL_PB_MAP_ID;
+	/* the ctx_state map, one source state per lane (lane i < 12 follows the automaton from state i: three instructions per
+	 * packet for the whole map instead of a 12-nibble loop on one lane -- the walk is issue-bound) */
+	uint32_t mst = lane < 12u ? lane : 0u;
 	uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, s0 = 0, s1 = 1, s2 = 2, s3 = 3, npk = 0;
 	bool bad = false;
 	while (p < end) {
 		const uint32_t w = p >> 6;
 		if (w != word) {
-			b.onwalk[word] = on; b.sp0[word] = sp;
-			for (uint32_t z = word + 1; z < w; z++) { b.onwalk[z] = 0; b.sp0[z] = 0; }
+			if (lane == 0) {
+				b.onwalk[word] = on; b.sp0[word] = sp;
+				for (uint32_t z = word + 1; z < w; z++) { b.onwalk[z] = 0; b.sp0[z] = 0; }
+			}
 			word = w; on = 0; sp = 0;
 		}
 		const uint64_t bit = 1ull << (p & 63u);
@@ -190,16 +195,14 @@ __global__ void __launch_bounds__(64) pb_mark(DevCtx c, Base2 b, PBuild pb, Cont
 				v0 = tv; s0 = ts;
 			}
 		}
-		uint64_t r = 0;
-#pragma unroll
-		for (uint32_t i = 0; i < 12; i++) {
-			const uint32_t s = (uint32_t)(map >> (4 * i)) & 15u;
-			r |= ((tbl >> (4 * s)) & 15ull) << (4 * i);
-		}
-		map = r;
+		mst = (uint32_t)(tbl >> (4u * mst)) & 15u;
 		p += len;
 		npk++;
 	}
+	uint64_t map = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 12; i++) map |= (uint64_t)rdlane(mst, i) << (4u * i);
+	if (lane != 0) return;
 	if (word < w_lim) {
 		b.onwalk[word] = on; b.sp0[word] = sp;
 		for (uint32_t z = word + 1; z < w_lim; z++) { b.onwalk[z] = 0; b.sp0[z] = 0; }

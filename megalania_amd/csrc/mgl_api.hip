@@ -277,7 +277,7 @@ static int launch_pbuild(mgl_sa* sa)
 	}
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
-	hipLaunchKernelGGL(pb_walk<false>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
+	hipLaunchKernelGGL(pb_walk, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
 	{
 		const uint32_t og = (pb.nblk + MGL_PB_OFF_ROWS - 1u) / MGL_PB_OFF_ROWS;
 		hipLaunchKernelGGL(pb_offsets_sum, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb);
@@ -285,7 +285,7 @@ static int launch_pbuild(mgl_sa* sa)
 		hipLaunchKernelGGL(pb_offsets, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb, total);
 	}
 	hipLaunchKernelGGL(pb_layout, dim3(1), dim3(64), 0, st, b, pb, ctl, total);
-	hipLaunchKernelGGL(pb_walk<true>, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
+	hipLaunchKernelGGL(pb_scatter, dim3(pb.nblk), dim3(256), b.ck_elems * 4u, st, b, pb, total);
 	hipLaunchKernelGGL(pb_sim, dim3((pb.seg_cap + 63) / 64), dim3(64), 0, st, c, b, pb);
 	hipLaunchKernelGGL(pb_sim_fix, dim3((total + 63) / 64), dim3(64), 0, st, c, b, pb);
 	hipLaunchKernelGGL(pb_ckpt, dim3((b.ck_elems + 63) / 64, (b.nck + MGL_PB_CK_ROWS - 1) / MGL_PB_CK_ROWS), dim3(64), 0, st, c, b);
@@ -539,7 +539,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	free_b2(sa->b2, false);
 	free_b2(sa->snap_lit, true); free_b2(sa->snap_best, true); dfree(sa->d_snap_meta);
 	dfree(sa->pb.exits); dfree(sa->pb.entry); dfree(sa->pb.gexits); dfree(sa->pb.gentry); dfree(sa->pb.gsum); dfree(sa->pb.ch_map); dfree(sa->pb.ch_vs); dfree(sa->pb.ch_pk); dfree(sa->pb.ch_state); dfree(sa->pb.tf_ctx); dfree(sa->pb.tf_dist); dfree(sa->pb.tf_pk);
-	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
+	dfree(sa->pb.st_in); dfree(sa->pb.hist); dfree(sa->pb.stage); dfree(sa->pb.stage_n); dfree(sa->pb.stage_over); dfree(sa->pb.acc); dfree(sa->pb.seg_off); dfree(sa->pb.unres);
 	{
 		mgl_sa::NbrSet& t = sa->alt;
 		dfree(t.nbr.cost); dfree(t.nbr.ndiffs); dfree(t.nbr.walked); dfree(t.nbr.win); dfree(t.nbr.win2); dfree(t.nbr.dpos); dfree(t.nbr.dold); dfree(t.nbr.dnew);
@@ -785,6 +785,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&pb.tf_pk, sizeof(uint32_t) * pb.nblk));
 			HIPCHK(hipMalloc(&pb.st_in, sizeof(uint32_t) * 8 * (size_t)pb.nblk));
 			HIPCHK(hipMalloc(&pb.hist, sizeof(uint32_t) * (size_t)pb.nblk * ckpt_elems));
+			HIPCHK(hipMalloc(&pb.stage, sizeof(uint64_t) * (size_t)pb.nblk * ((MGL_PB_STAGE_PER_POS << pb.shift) + 32u)));
+			HIPCHK(hipMalloc(&pb.stage_n, sizeof(uint32_t) * (size_t)pb.nblk));
+			HIPCHK(hipMalloc(&pb.stage_over, sizeof(uint32_t)));
+			HIPCHK(hipMemset(pb.stage_over, 0, sizeof(uint32_t)));
 			HIPCHK(hipMalloc(&pb.acc, sizeof(unsigned long long) * 8));
 			pb.seg_cap = b.pool_cap / MGL_PB_SEG + ckpt_elems + 64u;
 			HIPCHK(hipMalloc(&pb.seg_off, sizeof(uint32_t) * (ckpt_elems + 1)));

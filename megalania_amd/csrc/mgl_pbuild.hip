@@ -11,16 +11,16 @@
  *               effect on (ctx_state, rep distances) as a composable transform
  *   pb_scan     compose the transforms in block order: the walk state every block starts in
  *   pb_levels   summary levels of the special bitmap
- *   pb_walk<0>  one wavefront per block: special-state records, events per context
+ *   pb_walk     one wavefront per block: special-state records, events per context, every event staged with its rank
  *   pb_offsets  per context, exclusive scan of the per-block counts; pb_layout: chain offsets
- *   pb_walk<1>  the same walk again: every event to its slot of its context's chain
+ *   pb_scatter  one thread per staged event: to its slot of its context's chain
  *   pb_sim      per 2048-event chain segment: the probability before each event, the cost (+ pb_sim_fix)
  *   pb_ckpt     dense checkpoints read off the chains, written as 128-byte rows
  *   pb_finish   totals into Control
  *
- * Everything the walk needs at a block boundary is carried by the scan, so no kernel is serial in
- * the file size except pb_entries / pb_scan (one LDS-staged pointer chase, 32 bytes per KiB of
- * input).  Integer work throughout; results are identical to k_build's (tests/test_gpu_incremental.py).
+ * Everything the walk needs at a block boundary is carried by the scans, and both scans (entry offsets, walk states) are
+ * compositions of maps done in groups, so no kernel is serial in the file size.  Integer work throughout; results are
+ * identical to k_build's (tests/test_gpu_incremental.py).
  */
 #include "mgl_base2.h"
 
@@ -48,6 +48,9 @@ struct PBuild {
 	uint32_t* tf_pk;    /* nblk: packets starting in the block */
 	uint32_t* st_in;    /* nblk x 8: ctx_state, dists[4] at the block's first packet */
 	uint32_t* hist;     /* nblk x ck_elems: events per context, then their exclusive scan over blocks */
+	uint64_t* stage;    /* nblk x (16 << shift + 32): the events pb_walk found, for pb_scatter */
+	uint32_t* stage_n;  /* nblk: how many */
+	uint32_t* stage_over; /* one word: a block outgrew its staging area (cannot happen; checked) */
 	unsigned long long* acc; /* [0] cost [1] packets [2] final ctx_state [3..6] final dists [7] segments pb_sim_fix redid */
 	uint32_t* seg_off;  /* total + 1: first pb_sim segment of each context */
 	uint8_t* unres;     /* per segment: warm-up did not pin the probability, left to pb_sim_fix */
@@ -362,15 +365,25 @@ __global__ void __launch_bounds__(256) pb_levels(const uint64_t* lower, uint64_t
 
 /* One wavefront walks one block from its entry state.  SCATTER = false: special-state records +
  * events per context (pb.hist row) + direct-bit cost.  SCATTER = true: events into the chains. */
-template <bool SCATTER>
+/* One wavefront walks one block from its entry state: special-state records, events per context (pb.hist row), direct-bit
+ * cost -- and every event, with its rank among the block's events of its context, into the block's staging area
+ * (pos | ctx << 32 | bit << 46 | rank << 47), so that nothing has to walk the block a second time: once the per-context
+ * offsets are known, pb_scatter puts every staged event into its chain slot, one thread per event. */
+#define MGL_PB_STAGE_PER_POS 16u /* staged events per position of a block: the densest parse (length-2 far matches, 27 events each) has 13.5 */
+__device__ __forceinline__ uint64_t pb_stage_pack(uint32_t pos, uint32_t ctx, uint32_t bit, uint32_t rank)
+{
+	return (uint64_t)pos | ((uint64_t)ctx << 32) | ((uint64_t)bit << 46) | ((uint64_t)rank << 47);
+}
 __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t* cnt = (uint32_t*)smem;
 	const uint32_t lane = threadIdx.x, blk = blockIdx.x;
 	uint32_t* row = pb.hist + (size_t)blk * b.ck_elems;
-	if (SCATTER && *b.pool_top > b.pool_cap) return;
-	for (uint32_t i = lane; i < b.ck_elems; i += 64) cnt[i] = SCATTER ? (i < c.L.total ? b.ch_off[i] + row[i] : 0u) : 0u;
+	const uint32_t cap = (MGL_PB_STAGE_PER_POS << pb.shift) + 32u;
+	uint64_t* stage = pb.stage + (size_t)blk * cap;
+	uint32_t nst = 0; /* staged so far (uniform) */
+	for (uint32_t i = lane; i < b.ck_elems; i += 64) cnt[i] = 0u;
 	wave_sync();
 	Walk w;
 	walk_reset(w);
@@ -387,7 +400,7 @@ __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 		walk_window(w, c, b.slab, lane);
 		if (w.st.ctx_state < 7u) {
 			/* a run of plain literals: up to seven are planned at once, nine lanes each (is_match + the eight tree nodes);
-			 * their events take their chain slots packet by packet, because the packets share contexts (is_match, the top
+			 * their events take their ranks packet by packet, because the packets share contexts (is_match, the top
 			 * of the literal tree) and a chain is in position order -- the model replay of mgl_kernels2.hip does the same */
 			const uint32_t o = pos - w.wbase;
 			uint32_t lt, ld, ll;
@@ -412,15 +425,14 @@ __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 				mgl_plan pl;
 				mgl_plan_packet(&c.L, &sv, MGL_LITERAL, 0, 1, byte, 0, prev_byte, &pl);
 				if (!__ballot(active && pl.nev != 9u)) {
-					uint32_t ctx = 0, bit = 0;
+					uint32_t ctx = 0, bit = 0, k = 0;
 					if (active) mgl_plan_event(&pl, slot, &ctx, &bit);
 					for (uint32_t r = 0; r < take; r++) {
-						if (active && i == r) {
-							const uint32_t k = cnt[ctx]++;
-							if (SCATTER) { b.ch_pos[k] = p; b.ch_ev[k] = (uint16_t)(bit << 15); }
-						}
+						if (active && i == r) k = cnt[ctx]++;
 						wave_sync();
 					}
+					if (active && nst + lane < cap) stage[nst + lane] = pb_stage_pack(p, ctx, bit, k);
+					nst += 9u * take;
 					w.st.pos += take; w.st.ctx_state = lit_steps(w.st.ctx_state, take);
 					continue;
 				}
@@ -428,7 +440,7 @@ __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 		}
 		uint32_t type, dist, len;
 		pb_decode(walk_slab_at(w, pos), pos, c.n, type, dist, len);
-		if (!SCATTER && type != MGL_LITERAL && lane < 8) {
+		if (type != MGL_LITERAL && lane < 8) {
 			const uint32_t v = lane == 0 ? w.st.ctx_state : lane == 1 ? w.st.dists[0] : lane == 2 ? w.st.dists[1]
 			                 : lane == 3 ? w.st.dists[2] : lane == 4 ? w.st.dists[3] : 0u;
 			b.sp_state[(size_t)pos * 8 + lane] = v;
@@ -445,18 +457,38 @@ __global__ void __launch_bounds__(64) pb_walk(DevCtx c, Base2 b, PBuild pb)
 			uint32_t ctx, bit;
 			mgl_plan_event(&pl, lane, &ctx, &bit);
 			const uint32_t k = cnt[ctx]++; /* contexts of one packet are distinct: no conflict */
-			if (SCATTER) {
-				b.ch_pos[k] = pos;
-				b.ch_ev[k] = (uint16_t)(bit << 15);
-			}
+			if (nst + lane < cap) stage[nst + lane] = pb_stage_pack(pos, ctx, bit, k);
 		}
+		nst += pl.nev;
 		ndirect += pl.ndirect;
 		mgl_advance(&w.st, type, dist, len);
 	}
-	if (!SCATTER) {
-		wave_sync();
-		for (uint32_t i = lane; i < b.ck_elems; i += 64) row[i] = cnt[i];
-		if (lane == 0 && ndirect) atomicAdd(&pb.acc[0], (unsigned long long)ndirect << 11);
+	wave_sync();
+	for (uint32_t i = lane; i < b.ck_elems; i += 64) row[i] = cnt[i];
+	if (lane == 0) {
+		pb.stage_n[blk] = nst < cap ? nst : cap; /* (cap is never reached: see MGL_PB_STAGE_PER_POS) */
+		if (nst > cap) atomicOr(pb.stage_over, 1u);
+		if (ndirect) atomicAdd(&pb.acc[0], (unsigned long long)ndirect << 11);
+	}
+}
+/* every staged event to its slot: chain offset of its context + events of that context in earlier blocks + its rank in the block */
+__global__ void __launch_bounds__(256) pb_scatter(Base2 b, PBuild pb, uint32_t total)
+{
+	if (*b.pool_top > b.pool_cap) return;
+	const uint32_t blk = blockIdx.x;
+	const uint32_t cap = (MGL_PB_STAGE_PER_POS << pb.shift) + 32u;
+	const uint64_t* stage = pb.stage + (size_t)blk * cap;
+	const uint32_t* row = pb.hist + (size_t)blk * b.ck_elems;
+	const uint32_t n = pb.stage_n[blk];
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_first[]; /* per context: the slot of this block's first event of it */
+	for (uint32_t i = threadIdx.x; i < b.ck_elems; i += blockDim.x) s_first[i] = i < total ? b.ch_off[i] + row[i] : 0u;
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+		const uint64_t v = stage[e];
+		const uint32_t pos = (uint32_t)v, ctx = (uint32_t)(v >> 32) & 0x3FFFu, bit = (uint32_t)(v >> 46) & 1u, rank = (uint32_t)(v >> 47);
+		const uint32_t k = s_first[ctx] + rank;
+		b.ch_pos[k] = pos;
+		b.ch_ev[k] = (uint16_t)(bit << 15);
 	}
 }
 
@@ -683,6 +715,7 @@ __global__ void __launch_bounds__(64) pb_ckpt(DevCtx c, Base2 b)
 __global__ void pb_finish(PBuild pb, Control* ctl)
 {
 	if (threadIdx.x || blockIdx.x) return;
+	if (*pb.stage_over) atomicOr(&ctl->error_flags, MGL_ERR_WALK_OVERRUN); /* a block outgrew its staging area: cannot happen */
 	ctl->packets = pb.acc[1];
 	ctl->rebuild_cost = pb.acc[0];
 	ctl->final_ctx_state = (uint32_t)pb.acc[2];

@@ -136,6 +136,7 @@ struct mgl_sa {
 	uint64_t bulk_hold = 0;        /* AUTO: single steps left before bulk steps are tried again (their windows were too long) */
 	BulkBuf bulk;
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
+	uint32_t force_rollbacks = 0;  /* diagnostic: treat the next so many bulk steps that took moves as failed validations */
 	uint64_t bulk_rollbacks = 0;   /* bulk steps whose combined parse failed validation and was taken back (never seen) */
 	bool best_unverified = false;  /* packets_best came from another chain: checked when an epoch starts from it */
 	/* look-ahead (k_la_check): the next step's pick + window walk run beside this step's tail into the other buffer set */
@@ -1213,6 +1214,7 @@ static int launch_bulk_tail(mgl_sa* sa)
 	{
 		Control now;
 		if ((rc = read_ctl(sa, sa->base, &now))) return rc;
+		if (sa->force_rollbacks && now.taken) { sa->force_rollbacks--; now.error_flags |= MGL_ERR_BAD_PACKET; } /* diagnostic (mgl_debug_set key 3): exercise the net */
 		if (now.error_flags & MGL_ERR_BAD_PACKET) {
 			hipLaunchKernelGGL(k_bulk_rollback, dim3(64), dim3(256), 0, sa->stream, sa->nbr, sa->bulk, sa->base.v.slab);
 			HIPCHK(hipGetLastError());
@@ -1594,6 +1596,7 @@ extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
 		sa->big.chg_cap = (uint32_t)value;
 		return MGL_OK;
 	}
+	if (key == 3) { sa->force_rollbacks = (uint32_t)value; return MGL_OK; } /* the next `value` bulk steps that take moves are taken back as if their parse had failed validation */
 	return fail(MGL_EINVAL, "mgl_debug_set: unknown key");
 }
 

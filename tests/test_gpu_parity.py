@@ -524,3 +524,36 @@ def test_evolved_c2_neighbours_vs_oracle():
         assert int(ca[j]) == (c2 if ok else binding.INVALID_COST), j
     sa.close()
     full.close()
+
+
+def test_bulk_rollback_net_restores_the_step(golden_input):
+    """The bulk step's safety net (k_validate after the rebuild, k_bulk_rollback + a second rebuild when the combined
+    parse fails) has never fired on its own; mgl_debug_set key 3 makes the next bulk steps that took moves count as
+    failed.  A step taken back leaves slab, costs and best slab exactly as they were (only the step, iteration and
+    evaluation counters move on), and the chain carries on consistently afterwards."""
+    data = corpus.enwik_like(30000, 0x524F)
+    sa = binding.SA(data, accept="bulk", neighbours_per_step=512, seed=41, iters_per_epoch=10**7)
+    o = Oracle(data, dict_limit=0x400000)
+    sa.run(3)
+    before, cost_before = sa.current()
+    best_before, bcost_before = sa.best()
+    assert sa.L.mgl_debug_set(sa.h, 3, 2) == 0
+    st = sa.run(2)
+    assert st["bulk_rollbacks"] == 2 and st["accepted"] == 0 and st["bulk_steps"] == 2 and st["evaluations"] > 0
+    after, cost_after = sa.current()
+    best_after, bcost_after = sa.best()
+    assert cost_after == cost_before and (after == before).all()
+    assert bcost_after == bcost_before and (best_after == best_before).all()
+    assert cost_after == o.cost_slab(after.astype(literal_slab(1).dtype))["total"]
+    st = sa.run(4)
+    assert st["bulk_rollbacks"] == 0 and st["accepted"] > 0
+    cur, cost = sa.current()
+    assert cost < cost_before and cost == o.cost_slab(cur.astype(literal_slab(1).dtype))["total"]
+    bst, _ = sa.best()
+    assert lzma.decompress(binding.emit_stream(data, bst), format=lzma.FORMAT_ALONE) == data
+    # epochs from the best slab still work after a rollback
+    sa.begin_epoch(1, from_best=True)
+    st = sa.run(2)
+    cur, cost = sa.current()
+    assert cost == o.cost_slab(cur.astype(literal_slab(1).dtype))["total"]
+    sa.close()

@@ -26,8 +26,12 @@
 
 #define MGL_PB_MAX_SHIFT 10u  /* block = 2^shift positions, shift chosen per input size (8..10) */
 #define MGL_PB_MAX_BLOCK (1u << MGL_PB_MAX_SHIFT)
+#ifndef MGL_PB_SEG
 #define MGL_PB_SEG 2048u      /* pb_sim: events per thread ... */
+#endif
+#ifndef MGL_PB_WARM
 #define MGL_PB_WARM 1024u     /* ... after this many events of warm-up from both ends of the probability range */
+#endif
 #define MGL_PB_ENTRIES 273u /* a packet starting before a block boundary ends at most 272 bytes past it */
 #define MGL_PB_CK_ROWS 64u
 

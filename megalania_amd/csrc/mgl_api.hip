@@ -790,7 +790,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&pb.stage_n, sizeof(uint32_t) * (size_t)pb.nblk));
 			HIPCHK(hipMalloc(&pb.stage_over, sizeof(uint32_t)));
 			HIPCHK(hipMemset(pb.stage_over, 0, sizeof(uint32_t)));
-			HIPCHK(hipMalloc(&pb.acc, sizeof(unsigned long long) * 8));
+			HIPCHK(hipMalloc(&pb.acc, sizeof(unsigned long long) * 16));
+			HIPCHK(hipMemset(pb.acc, 0, sizeof(unsigned long long) * 16));
 			pb.seg_cap = b.pool_cap / MGL_PB_SEG + ckpt_elems + 64u;
 			HIPCHK(hipMalloc(&pb.seg_off, sizeof(uint32_t) * (ckpt_elems + 1)));
 			HIPCHK(hipMalloc(&pb.unres, pb.seg_cap));

@@ -55,7 +55,7 @@ struct PBuild {
 	uint64_t* stage;    /* nblk x (16 << shift + 32): the events pb_walk found, for pb_scatter */
 	uint32_t* stage_n;  /* nblk: how many */
 	uint32_t* stage_over; /* one word: a block outgrew its staging area (cannot happen; checked) */
-	unsigned long long* acc; /* [0] cost [1] packets [2] final ctx_state [3..6] final dists [7] segments pb_sim_fix redid */
+	unsigned long long* acc; /* [0] cost [1] packets [2] final ctx_state [3..6] final dists [7] segments pb_sim_fix redid [8] segments pb_sim left to it */
 	uint32_t* seg_off;  /* total + 1: first pb_sim segment of each context */
 	uint8_t* unres;     /* per segment: warm-up did not pin the probability, left to pb_sim_fix */
 	uint32_t seg_cap;
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64) pb_scan(PBuild pb)
 	if (lane == 0) {
 		pb.acc[0] = 0;
 		pb.acc[1] = packets;
-		pb.acc[2] = cs; pb.acc[3] = d0; pb.acc[4] = d1; pb.acc[5] = d2; pb.acc[6] = d3; pb.acc[7] = 0;
+		pb.acc[2] = cs; pb.acc[3] = d0; pb.acc[4] = d1; pb.acc[5] = d2; pb.acc[6] = d3; pb.acc[7] = 0; pb.acc[8] = 0;
 	}
 }
 __global__ void __launch_bounds__(256) pb_scan_fill(PBuild pb)
@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(64) pb_sim(DevCtx c, Base2 b, PBuild pb)
 			p = plo;
 		}
 		pb.unres[seg] = ok ? 0 : 1;
+		if (!ok) atomicAdd(&pb.acc[8], 1ull); /* pb_sim_fix returns at once when nothing is left to it (as good as always) */
 		if (ok) {
 			pb_sim_range(ev, i0, i1, p, cost, T);
 			if (i1 == len) { ev[len] = (uint16_t)p; b.ch_pos[off + len] = MGL_POS_INF; }
@@ -643,6 +644,7 @@ __global__ void __launch_bounds__(64) pb_sim(DevCtx c, Base2 b, PBuild pb)
 /* the segments pb_sim could not start: in chain order, from the entry before them */
 __global__ void __launch_bounds__(64) pb_sim_fix(DevCtx c, Base2 b, PBuild pb)
 {
+	if (pb.acc[8] == 0) return; /* every segment started exact */
 	__shared__ uint16_t T[2048];
 	for (uint32_t i = threadIdx.x; i < 2048; i += 64) T[i] = c.cost_tbl[i];
 	__syncthreads();

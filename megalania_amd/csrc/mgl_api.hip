@@ -148,6 +148,7 @@ struct mgl_sa {
 	uint32_t* d_la_list = nullptr;
 	uint32_t* d_la_hdr = nullptr;  /* [0] neighbours to evaluate again, [1] second-pass entries of the speculative launch */
 	hipStream_t stream5 = nullptr, stream6 = nullptr;
+	hipEvent_t ev_val = nullptr; /* a bulk step's validation beside its build */
 	hipEvent_t ev_la_check = nullptr, ev_la_zero = nullptr, ev_redo = nullptr, ev_spec[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
@@ -257,7 +258,7 @@ static int launch_rebuild(mgl_sa* sa, BaseMem& b, int from_dirty, uint64_t* cum,
 }
 /* (re)derive everything that hangs off the current base slab */
 /* the base structures of the slab from scratch, block-parallel (mgl_pbuild.hip) */
-static int launch_pbuild(mgl_sa* sa)
+static int launch_pbuild(mgl_sa* sa, bool validate_beside = false)
 {
 	const DevCtx& c = sa->ctx;
 	Base2& b = sa->b2;
@@ -279,6 +280,14 @@ static int launch_pbuild(mgl_sa* sa)
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
 	hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, st, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
 	hipLaunchKernelGGL(pb_walk, dim3(pb.nblk), dim3(64), b.ck_elems * 4u, st, c, b, pb);
+	if (validate_beside) {
+		/* a bulk step's check of the new parse (every packet against the input) needs the bitmaps and the special-state
+		 * records, which exist from here on: it runs on the second stream beside the rest of the build */
+		HIPCHK(hipEventRecord(sa->ev_fork, st));
+		HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_fork, 0));
+		hipLaunchKernelGGL(k_validate, dim3((sa->ctx.n + 255u) / 256u), dim3(256), 0, sa->stream2, sa->ctx, sa->b2, sa->base.ctl);
+		HIPCHK(hipEventRecord(sa->ev_val, sa->stream2));
+	}
 	{
 		const uint32_t og = (pb.nblk + MGL_PB_OFF_ROWS - 1u) / MGL_PB_OFF_ROWS;
 		hipLaunchKernelGGL(pb_offsets_sum, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb);
@@ -291,6 +300,7 @@ static int launch_pbuild(mgl_sa* sa)
 	hipLaunchKernelGGL(pb_sim_fix, dim3((total + 63) / 64), dim3(64), 0, st, c, b, pb);
 	hipLaunchKernelGGL(pb_ckpt, dim3((b.ck_elems + 63) / 64, (b.nck + MGL_PB_CK_ROWS - 1) / MGL_PB_CK_ROWS), dim3(64), 0, st, c, b);
 	hipLaunchKernelGGL(pb_finish, dim3(1), dim3(64), 0, st, pb, ctl);
+	if (validate_beside) HIPCHK(hipStreamWaitEvent(st, sa->ev_val, 0));
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }
@@ -568,6 +578,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	if (sa->stream3) (void)hipStreamDestroy(sa->stream3);
 	for (auto& e : sa->ev_rest) if (e) (void)hipEventDestroy(e);
 	if (sa->ev_sim) (void)hipEventDestroy(sa->ev_sim);
+	if (sa->ev_val) (void)hipEventDestroy(sa->ev_val);
 	if (sa->ev_fork) (void)hipEventDestroy(sa->ev_fork);
 	if (sa->ev_join) (void)hipEventDestroy(sa->ev_join);
 	if (sa->stream) (void)hipStreamDestroy(sa->stream);
@@ -584,6 +595,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipStreamCreate(&sa->stream3));
 	for (auto& e : sa->ev_rest) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_sim, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&sa->ev_val, hipEventDisableTiming));
 	/* measured: + 8 % on the 10 MB input, nothing on the 100 KB one (its kernels are too short to overlap) */
 	sa->halves = getenv("MGL_HALVES") ? (uint32_t)atoi(getenv("MGL_HALVES")) : (n > (1u << 20) ? 2u : 1u);
 	if (sa->halves < 1 || sa->halves > 8) sa->halves = 1;
@@ -1206,12 +1218,11 @@ static int launch_bulk_tail(mgl_sa* sa)
 	}
 	hipLaunchKernelGGL(k_bulk_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, a);
 	HIPCHK(hipGetLastError());
-	int rc = launch_pbuild(sa);
+	int rc = launch_pbuild(sa, sa->incremental);
 	if (rc) return rc;
 	/* the taken set is checked after the fact (soft window ends rest on an argument about rep distances, not on a
 	 * proof for every coincidence of values): every packet of the new parse against the input; a parse that fails is
 	 * taken back as a whole.  One small read-back per bulk step (a bulk step is a rebuild: milliseconds) */
-	if ((rc = launch_validate(sa))) return rc;
 	{
 		Control now;
 		if ((rc = read_ctl(sa, sa->base, &now))) return rc;

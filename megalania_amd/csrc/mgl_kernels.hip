@@ -820,6 +820,7 @@ __device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, 
 			const uint32_t p = nb.pos;
 			const mgl_pk pk = uni64(journal_or_base(jn, slab, p, lane));
 			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk);
+			if (count > 0 && pk != uni64(slab[p])) wsoft = 0xFFFFFFFFu; /* a changed packet: the soft window reaches behind it */
 			if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) {
 				/* not when it is the base's own packet reading a slot that holds the same distance in both walks */
 				const uint32_t slot = ntype == MGL_SHORT_REP ? 0u : ndist;

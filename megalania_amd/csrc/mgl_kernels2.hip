@@ -1047,6 +1047,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 					if (!first_packet && pk != old) {
 						const mgl_pk base_old = (second_set && p == pos + 1) ? uni64(b.slab[p]) : old;
 						journal_set(jn, p, base_old, pk, lane);
+						wsoft = 0xFFFFFFFFu; /* a changed packet (a SHORT_REP the repair turned into a literal, say): the soft window reaches behind it */
 					}
 					first_packet = false;
 					walked++;

@@ -926,6 +926,8 @@ static window_info window_end(const orc_ctx* c, const orc_packet* slab, const jo
 			wi.walked++;
 			const size_t p = nb.pos;
 			const orc_packet pk = slab[p];
+			/* a packet the move changed (a SHORT_REP the repair turned into a literal, say): the soft window reaches behind it */
+			if (count > 0 && !pk_eq(pk, base_at(slab, jn, p))) wi.soft_end = (size_t)-1;
 			/* a rep packet reads a rep distance: the soft window reaches at least to behind it -- unless it is the base's own
 			 * packet at this position reading a slot that holds the same distance in both walks (then the move has no part
 			 * in what it codes) */
@@ -1087,6 +1089,9 @@ static int parse_is_valid(const orc_ctx* c, const orc_packet* slab)
 /* bulk steps of orc_sa_batched whose combined parse failed the check and was taken back (tests: the window rule should never need this net) */
 static uint64_t g_bulk_rollbacks;
 uint64_t orc_bulk_rollbacks(void) { return g_bulk_rollbacks; }
+/* slab entries two taken journals of one step both wrote (must stay 0: the selection's windows cover every changed packet) */
+static uint64_t g_bulk_overlaps;
+uint64_t orc_bulk_overlaps(void) { return g_bulk_overlaps; }
 
 static int windows_conflict(const uint32_t* x, const uint32_t* y)
 {
@@ -1196,7 +1201,13 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 		}
 		for (uint32_t j = 0; j < K; j++) {
 			if (!take[j]) continue;
-			for (size_t e = 0; e < nd[j]; e++) slab[diffs[(size_t)j * ORC_MAX_JOURNAL + e].position] = diffs[(size_t)j * ORC_MAX_JOURNAL + e].new_packet;
+			for (size_t e = 0; e < nd[j]; e++) {
+				const orc_diff* d = &diffs[(size_t)j * ORC_MAX_JOURNAL + e];
+				/* taken journals must touch disjoint entries (the device writes them in parallel): an entry that no longer
+				 * holds what this journal replaced was written by another one */
+				if (!pk_eq(slab[d->position], d->old_packet)) g_bulk_overlaps++;
+				slab[d->position] = d->new_packet;
+			}
 		}
 		if (ntaken && bulk && !parse_is_valid(c, slab)) {
 			/* the safety net of the soft window ends: a combination that is not a valid parse is taken back as a whole

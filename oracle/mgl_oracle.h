@@ -93,6 +93,7 @@ int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step,
  * best acceptable neighbour, 1 = take every acceptable neighbour that is the best of its window.
  * trace (nullable) gets 4 u64 per step: smallest acceptable cost (or ~0), neighbours accepted,
  * acceptable neighbours, current cost after the step. */
+uint64_t orc_bulk_overlaps(void);  /* slab entries written by two taken journals of one bulk step (must stay 0) */
 uint64_t orc_bulk_rollbacks(void); /* bulk steps taken back by the validity check since the library was loaded */
 int orc_sa_batched(orc_ctx* c, orc_packet* slab_io, orc_packet* best_io, uint64_t* cur_io,
                    uint64_t* best_cost_io, uint64_t seed, uint32_t K, unsigned phase,

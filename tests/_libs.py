@@ -106,6 +106,8 @@ class Oracle:
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             L.orc_bulk_rollbacks.restype = C.c_uint64
             L.orc_bulk_rollbacks.argtypes = []
+            L.orc_bulk_overlaps.restype = C.c_uint64
+            L.orc_bulk_overlaps.argtypes = []
             L.orc_neighbour_ex.restype = C.c_int
             L.orc_neighbour_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -228,6 +230,10 @@ class Oracle:
     def bulk_rollbacks(self) -> int:
         """bulk steps the oracle took back since the library was loaded (a process-wide counter)"""
         return int(self.L.orc_bulk_rollbacks())
+
+    def bulk_overlaps(self) -> int:
+        """slab entries that two taken journals of one bulk step both wrote, since the library was loaded"""
+        return int(self.L.orc_bulk_overlaps())
 
     def emit(self, slab) -> bytes:
         cap = 2 * self.n + 1024

@@ -143,25 +143,45 @@ def test_batched_semantics_selfconsistent():
         assert lzma.decompress(o.emit(kept), format=lzma.FORMAT_ALONE) == data
 
 
-@pytest.mark.parametrize("name,seed", [("lorem", 1), ("lorem", 2), ("enwik", 3), ("enwik", 4), ("runs", 5), ("runs", 6), ("zeros", 7)])
+def doubled_letters(seed, n):
+    """words over a small alphabet with letters doubled at random: SHORT_REP packets everywhere, and repairs that turn them
+    back into literals far behind the mutated packet (the case the soft window end has to cover)"""
+    import random
+    r = random.Random(seed)
+    out = bytearray()
+    words = [bytes(r.choice(b"abcdefgh") for _ in range(r.randint(2, 6))) for _ in range(12)]
+    while len(out) < n:
+        for ch in r.choice(words):
+            out.append(ch)
+            if r.random() < 0.45:
+                out.append(ch)
+        if r.random() < 0.3:
+            out += b"  "
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("name,seed", [("lorem", 1), ("lorem", 2), ("enwik", 3), ("enwik", 4), ("runs", 5), ("runs", 6), ("zeros", 7),
+                                       ("doubled", 1), ("doubled", 5), ("doubled", 9)])
 def test_bulk_steps_on_the_oracle_never_need_the_rollback(name, seed):
     """The bulk step's selection rests on a local argument about windows and rep distances; the
-    oracle checks every combined parse and takes a failing step back as a whole.  On repetitive, text-like and run-heavy
+    oracle checks every combined parse and takes a failing step back as a whole, and counts slab entries that two taken
+    journals of a step both write (the device writes them in parallel: with soft window ends that did not reach behind
+    every *changed* packet the "doubled" inputs produce such entries, and the device's result depended on timing).  On repetitive, text-like and run-heavy
     inputs (rep packets everywhere) that net is never needed, the exact cost the step reports is a full walk's, and the
     stream decodes -- CPU only, so it runs wherever the tests run."""
     from megalania_amd import corpus
     data = {"lorem": corpus.lorem(2200), "enwik": corpus.enwik_like(3000, 0x77 + seed),
             "runs": b"a" * 300 + b"ab" * 200 + bytes(range(64)) * 3 + b"a" * 120 + b"abcabcabd" * 40,
-            "zeros": bytes(900) + b"\x01\x02" * 50 + bytes(400)}[name]
+            "zeros": bytes(900) + b"\x01\x02" * 50 + bytes(400), "doubled": doubled_letters(seed, 2600)}[name]
     n = len(data)
     o = Oracle(data)
     slab, best = literal_slab(n), literal_slab(n)
-    before = o.bulk_rollbacks()
-    K, steps = 48, 36
+    before, over_before = o.bulk_rollbacks(), o.bulk_overlaps()
+    K, steps = (96, 60) if name == "doubled" else (48, 36)
     cur = best_cost = 0
     taken = 0
     for s0 in range(0, steps, 6):
-        res = o.sa_batched(slab, best, cur, best_cost, seed=seed * 1000003, K=K, phase=0, iters_per_epoch=n,
+        res = o.sa_batched(slab, best, cur, best_cost, seed=(seed * 7717 if name == "doubled" else seed * 1000003), K=K, phase=0, iters_per_epoch=n,
                            step_begin=s0, step_end=s0 + 6, iter0=s0 * K, modes=[1] * 6)
         cur, best_cost = res["cur"], res["best"]
         taken += int(res["trace"][:, 1].sum())
@@ -169,4 +189,5 @@ def test_bulk_steps_on_the_oracle_never_need_the_rollback(name, seed):
         assert best_cost == o.cost_slab(best)["total"] <= cur
         assert lzma.decompress(o.emit(slab), format=lzma.FORMAT_ALONE) == data
     assert o.bulk_rollbacks() == before
+    assert o.bulk_overlaps() == over_before  # no slab entry written by two taken journals (the device writes them in parallel)
     assert taken >= 12  # the steps did take moves (several per step on the text-like inputs)

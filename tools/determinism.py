@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """Two chains with the same seed but different launch orders (MGL_HALVES 2 / 3; on small inputs split form / one-kernel form)
 must stay identical: every taken journal of a bulk step is written in parallel, every accepted move folded in place.
-   python tools/determinism.py c3 [steps=1500] [chunk=50]"""
+   python tools/determinism.py c3 [steps=1500] [chunk=50] [accept=auto] [greedy=0]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from megalania_amd import binding, corpus
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+accept = sys.argv[4] if len(sys.argv) > 4 else "auto"
+greedy = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}[cfg]
 data, _ = corpus.config_input(cfg)
 props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
 def make(env):
     for k in ("MGL_HALVES", "MGL_NO_ADAPT", "MGL_NO_SPLIT"): os.environ.pop(k, None)
     os.environ.update(env)
-    sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=len(data), **props)
+    sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=len(data), accept=accept, **props)
+    if greedy:
+        sa.seed_greedy(greedy)
     for k in env: os.environ.pop(k, None)
     return sa
 big = len(data) > (1 << 20)

@@ -598,3 +598,26 @@ def test_bulk_steps_do_not_depend_on_timing(monkeypatch):
     assert lzma.decompress(binding.emit_stream(data, ca), format=lzma.FORMAT_ALONE) == data
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("seed", [1, 5])
+def test_bulk_trajectory_vs_oracle_on_short_rep_heavy_input(seed):
+    """Bulk steps, device against oracle step by step, on the input family where repairs turn SHORT_REP packets far behind
+    the mutated packet back into literals (tests/test_oracle_golden.py:doubled_letters; these seeds made two taken
+    journals write one slab entry before the soft window end reached behind every changed packet)."""
+    from test_oracle_golden import doubled_letters
+    data = doubled_letters(seed, 2600)
+    n, K, steps = len(data), 96, 60
+    sa = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=seed * 7717, iters_per_epoch=n)
+    o = Oracle(data, dict_limit=0x400000)
+    slab, best = literal_slab(n), literal_slab(n)
+    before = o.bulk_overlaps()
+    ref = o.sa_batched(slab, best, 0, 0, seed * 7717, K, 0, n, 0, steps, modes=np.ones(steps, dtype=np.uint8))
+    assert o.bulk_overlaps() == before
+    for s in range(steps):
+        st = sa.run(1)
+        assert st["current_cost"] == int(ref["trace"][s, 3]) and st["accepted"] == int(ref["trace"][s, 1]), s
+    cur, cost = sa.current()
+    assert cost == ref["cur"] and as_list(cur) == as_list(slab)
+    assert lzma.decompress(binding.emit_stream(data, sa.best()[0]), format=lzma.FORMAT_ALONE) == data
+    sa.close()

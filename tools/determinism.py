@@ -14,7 +14,7 @@ K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}[cfg]
 data, _ = corpus.config_input(cfg)
 props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
 def make(env):
-    for k in ("MGL_HALVES", "MGL_NO_ADAPT", "MGL_NO_SPLIT"): os.environ.pop(k, None)
+    for k in ("MGL_HALVES", "MGL_NO_ADAPT", "MGL_NO_SPLIT", "MGL_LOOKAHEAD"): os.environ.pop(k, None)
     os.environ.update(env)
     sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=len(data), accept=accept, **props)
     if greedy:
@@ -23,7 +23,11 @@ def make(env):
     return sa
 big = len(data) > (1 << 20)
 a = make({"MGL_HALVES": "2", "MGL_NO_ADAPT": "1"} if big else {"MGL_NO_ADAPT": "1"})
-b = make({"MGL_HALVES": "3", "MGL_NO_ADAPT": "1"} if big else {"MGL_NO_SPLIT": "1"})
+b_env = {"MGL_HALVES": "3", "MGL_NO_ADAPT": "1"} if big else {"MGL_NO_SPLIT": "1"}
+if os.environ.get("MGL_DET_LOOKAHEAD"):  # second chain: the opt-in look-ahead instead (split form pinned)
+    os.environ.pop("MGL_DET_LOOKAHEAD")
+    b_env = {"MGL_LOOKAHEAD": "1", "MGL_NO_ADAPT": "1"}
+b = make(b_env)
 done = 0
 while done < steps:
     sa_, sb_ = a.run(chunk), b.run(chunk); done += chunk

@@ -342,7 +342,9 @@ static int launch_apply(mgl_sa* sa)
 }
 /* diagnostic (MGL_TRACE=1): name every launch of the neighbour evaluation on stderr and wait for the device after it, so that a
  * faulting kernel is the last one named */
-#define NBR_TRACE(name) do { if (getenv("MGL_TRACE")) { fprintf(stderr, "[mgl] %s\n", name); hipError_t e_ = hipDeviceSynchronize(); if (e_ != hipSuccess) fprintf(stderr, "[mgl] %s -> %s\n", name, hipGetErrorString(e_)); } } while (0)
+/* diagnostic switches of the launch path, read once */
+static const bool g_trace = getenv("MGL_TRACE") != nullptr, g_prof_big = getenv("MGL_PROF_BIG") != nullptr, g_big_inline_sim = getenv("MGL_BIG_INLINE_SIM") != nullptr;
+#define NBR_TRACE(name) do { if (g_trace) { fprintf(stderr, "[mgl] %s\n", name); hipError_t e_ = hipDeviceSynchronize(); if (e_ != hipSuccess) fprintf(stderr, "[mgl] %s -> %s\n", name, hipGetErrorString(e_)); } } while (0)
 static mgl_sa::NbrSet cur_set(const mgl_sa* sa)
 {
 	mgl_sa::NbrSet t = { sa->nbr, sa->d_pickrec, sa->d_pickstate, sa->big.sim_hdr, sa->big.sim_keys, sa->big.sim_pos, sa->d_todo, sa->d_counts };
@@ -377,7 +379,7 @@ static int launch_pick_rest(mgl_sa* sa, const mgl_sa::NbrSet& t, uint64_t step_o
 		                   (unsigned long long*)nullptr, g, t.pickrec, j0, j1, t.pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_PICK>");
 		hipLaunchKernelGGL((k_neighbours2<false, MGL_NBR_REST>), dim3(j1 - j0), dim3(64), sa->per_wave_rest, st, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, t.nbr, sa->per_wave_rest, t.todo, t.counts,
-		                   getenv("MGL_PROF_BIG") ? (unsigned long long*)nullptr : sa->d_prof, g, t.pickrec, j0, j1, t.pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_REST>");
+		                   g_prof_big ? (unsigned long long*)nullptr : sa->d_prof, g, t.pickrec, j0, j1, t.pickstate); NBR_TRACE("k_neighbours2<false, MGL_NBR_REST>");
 		HIPCHK(hipEventRecord(done[h], st));
 	}
 	HIPCHK(hipGetLastError());
@@ -468,7 +470,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	BigScratch big_now = sa->big;
 	big_now.lds_cache = 1u;
 	const uint32_t big_lds = sa->nbr2_lds + 12u * MGL_BIG_CAP; /* + a copy of both lists for the re-simulations */
-	if (!split_now || getenv("MGL_BIG_INLINE_SIM")) big_now.sim_hdr2 = nullptr; /* the one-kernel form has no k_sim launch to hand over to */
+	if (!split_now || g_big_inline_sim) big_now.sim_hdr2 = nullptr; /* the one-kernel form has no k_sim launch to hand over to */
 	const bool la_step = from_lookahead && split_now;
 	if (la_step) {
 		/* first the entries the speculative launch made (their count is fixed since k_la_check; the ones evaluated again are passed by) ... */
@@ -482,7 +484,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	} else {
 		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
-		                   getenv("MGL_PROF_BIG") ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL>");
+		                   g_prof_big ? sa->d_prof : (unsigned long long*)nullptr, big_now, (sa->split_nbr && !sa->form_single) ? sa->d_pickrec : (uint4*)nullptr, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL>");
 	}
 	if (la_step) {
 		/* ... then, once the fresh evaluations are through, the entries they added */

@@ -505,6 +505,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 		BigScratch late = sa->big;
 		late.todo_in = sa->d_todo3; late.todo_in_count = sa->d_counts + 4; late.sim_hdr2 = nullptr; late.lds_cache = 1u;
+		late.cont = nullptr; /* its list is another one: the slots' saved walks belong to the second pass proper */
 		hipLaunchKernelGGL((k_neighbours2<true, MGL_NBR_FULL>), dim3(bigblocks < 64u ? bigblocks : 64u), dim3(64 * sa->waves_per_block2), big_lds, sa->stream, sa->ctx,
 		                   sa->b2, sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave2, sa->d_todo2, sa->d_counts + 1,
 		                   (unsigned long long*)nullptr, late, sa->d_pickrec, 0u, K, sa->d_pickstate); NBR_TRACE("k_neighbours2<true, MGL_NBR_FULL>");
@@ -568,6 +569,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
+	dfree(sa->big.cont);
 	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->big.sim_slot2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
@@ -918,6 +920,12 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&g.sim_hdr2, sizeof(uint4) * (size_t)K));
 			HIPCHK(hipMalloc(&g.sim_slot2, sizeof(uint32_t) * (size_t)K));
 			HIPCHK(hipMemset(g.sim_hdr2, 0xFF, sizeof(uint4) * (size_t)K));
+			/* continuation records: the second half saves a walk that stops at a repair pick, the second pass resumes it
+			 * (not beside the look-ahead, whose speculative launch would write the slots the running second pass reads) */
+			if (getenv("MGL_NO_CONT") == nullptr && getenv("MGL_LOOKAHEAD") == nullptr) {
+				HIPCHK(hipMalloc(&g.cont, sizeof(uint32_t) * MGL_CONT_WORDS * (size_t)g.slots));
+				HIPCHK(hipMemset(g.cont, 0, sizeof(uint32_t) * MGL_CONT_WORDS * (size_t)g.slots));
+			}
 			/* look-ahead: a second set of everything pick + walk write, the check's list and marks, two more streams */
 			/* Opt-in (MGL_LOOKAHEAD=1): exact (tests/test_gpu_parity.py runs it against the plain order), but slower on MI355X as
 			 * measured (c3: 1.58 ms per step against 1.37, profiles/r02_lookahead_c3.txt): the pick kernel is bound by LDS capacity

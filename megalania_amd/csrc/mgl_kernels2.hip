@@ -669,7 +669,13 @@ struct BigScratch {
 	const uint32_t* la_list; const uint32_t* la_count;
 	const uint8_t* la_mark; const uint32_t* la_spec_count;
 	const uint32_t* todo_first; /* second pass over the list's tail only: entries from *todo_first on (nullptr: all) */
+	/* continuation records, one per scratch slot (MGL_CONT_WORDS u32 each): a second-half wavefront whose repair needs a top-K pick
+	 * saves its walk here (state, journal; its change lists go to the slot's list area) and the second pass resumes it at the
+	 * pick instead of evaluating the neighbour again from its target.  nullptr: no continuations (restart, as before) */
+	uint32_t* cont;
 };
+#define MGL_CONT_WORDS 368u       /* 48 header words | 64 journal positions | 64 old packets | 64 new packets */
+#define MGL_CONT_MAGIC 0x434F4E54u
 /* MODE: the regular launch is split in two so that each half needs fewer registers and more
  * wavefronts fit a SIMD (top-K is the register hog):
  *   MGL_NBR_PICK  everything up to the mutated packet: target, walk state, and -- unless the
@@ -753,6 +759,10 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 
 	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
 	NbrRng rng; rng.key = mgl_rng_key(seed, gstep, j); rng.n = 0;
+	/* second pass: a walk the second half saved at its repair pick (same neighbour, same slot) is taken up there */
+	uint32_t* const crec = (BIG && big.cont != nullptr) ? big.cont + (size_t)slot * MGL_CONT_WORDS : nullptr;
+	bool resumed = false;
+	if (BIG && crec != nullptr) resumed = uni(crec[0]) == MGL_CONT_MAGIC && uni(crec[1]) == j;
 
 	/* target (same rule as the full-walk path) and the walk state there; the second half of a split
 	 * launch takes both from the first half's record instead of drawing and searching again */
@@ -765,6 +775,10 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		target = s0.x; rng.n = s0.y;
 		nb.pos = target; nb.ctx_state = s0.z;
 		nb.dists[0] = s0.w; nb.dists[1] = s1.x; nb.dists[2] = s1.y; nb.dists[3] = s1.z;
+	} else if (BIG && resumed) {
+		target = uni(crec[2]);
+		nb.pos = uni(crec[3]); nb.ctx_state = uni(crec[4]);
+		nb.dists[0] = uni(crec[5]); nb.dists[1] = uni(crec[6]); nb.dists[2] = uni(crec[7]); nb.dists[3] = uni(crec[8]);
 	} else {
 		uint32_t mydraw = lane < 32 ? mgl_rng_draw(rng.key, lane) % c.n : 0;
 		bool on = lane < 32 && ((b.onwalk[mydraw >> 6] >> (mydraw & 63u)) & 1ull);
@@ -803,7 +817,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	bool second_set = false, mutated = false;
 	prof_mark(prof, 0, lane); /* state at target */
 	if (c.diag_stop == 1) { if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = first; } return; }
-	if (pos + 1 < c.n && (nbr_draw(rng) % 2u) == 0) {
+	if (!(BIG && resumed) && pos + 1 < c.n && (nbr_draw(rng) % 2u) == 0) {
 		const mgl_pk second = uni64(b.slab[pos + 1]);
 		const uint32_t ft = mgl_pk_type(first), flen = mgl_pk_len(first);
 		const uint32_t st = mgl_pk_type(second), slen = mgl_pk_len(second), sdist = mgl_pk_dist(second);
@@ -852,6 +866,29 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	bool first_packet = true;
 	uint32_t guard = 0;
 	/* the second pass, too, takes the mutation's pick from the first half when there was one */
+	if (BIG && resumed) {
+		/* the saved walk: everything the loop below carries from one packet to the next */
+		bs.pos = uni(crec[9]); bs.ctx_state = uni(crec[10]);
+		bs.dists[0] = uni(crec[11]); bs.dists[1] = uni(crec[12]); bs.dists[2] = uni(crec[13]); bs.dists[3] = uni(crec[14]);
+		count = uni(crec[15]); walked = uni(crec[16]); npicks = uni(crec[17]); wsoft = uni(crec[18]); taint = uni(crec[19]); dep = uni(crec[20]);
+		rng.n = uni(crec[21]); guard = uni(crec[22]); jn.count = uni(crec[23]); ch.n_ins = uni(crec[24]); ch.n_rem = uni(crec[25]);
+		const uint32_t fl = uni(crec[26]);
+		pick_best = (fl & 1u) != 0; second_set = (fl & 2u) != 0;
+		pick_inc = (mgl_pk)uni(crec[28]) | ((mgl_pk)uni(crec[29]) << 32);
+		resume_old = (mgl_pk)uni(crec[30]) | ((mgl_pk)uni(crec[31]) << 32);
+		m_second = (mgl_pk)uni(crec[32]) | ((mgl_pk)uni(crec[33]) << 32);
+		ch.direct = (int64_t)((uint64_t)uni(crec[34]) | ((uint64_t)uni(crec[35]) << 32));
+		if (lane < jn.count) {
+			jn.pos[lane] = crec[48u + lane];
+			jn.old[lane] = reinterpret_cast<const mgl_pk*>(crec + 112u)[lane];
+			jn.neu[lane] = reinterpret_cast<const mgl_pk*>(crec + 240u)[lane];
+		}
+		wave_sync();
+		if (lane == 0) crec[0] = 0u; /* taken */
+		pick_pos = nb.pos;
+		mutated = true; pick_is_mutation = false; first_packet = false;
+		phase = P_MODEL;
+	}
 	if ((MODE == MGL_NBR_REST || (BIG && pickrec != nullptr)) && !mutated) { /* the host passes the pick records only when the split form ran */
 		const uint4 rec = pickrec[j];
 		if (!(rec.w & 1u)) { generate_failed = true; phase = P_OUT; }
@@ -865,7 +902,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 	}
 
 	for (;;) {
-		if (MODE == MGL_NBR_REST && (phase == P_MODEL || phase == P_TOPK)) { ch.overflow = true; phase = P_OUT; continue; } /* repair pick: next pass */
+		if (MODE == MGL_NBR_REST && (phase == P_MODEL || phase == P_TOPK)) { ch.overflow = true; phase = P_OUT; continue; } /* repair pick without a continuation record: the next pass evaluates the neighbour again */
 		if (MODE != MGL_NBR_REST && phase == P_MODEL) {
 			/* the adaptive model the neighbour has at pick_pos: base model before the first base
 			 * packet at or after it (dense checkpoint + replay of < 64 bytes of base packets) ... */
@@ -1037,6 +1074,45 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 									mgl_advance(&bs, mgl_pk_type(bpk), mgl_pk_dist(bpk), mgl_pk_len(bpk));
 								}
 								if (ch.overflow) break;
+								if (MODE == MGL_NBR_REST && big.cont != nullptr) {
+									/* the second half holds no top-K code: the walk as it stands goes to a continuation record (state, journal;
+									 * the change lists to the slot's list area) and the second pass takes it up at this pick.  Saved here, where
+									 * everything is live anyway, so that the walk loop carries no value for it */
+									uint32_t slot2 = 0;
+									if (lane == 0) {
+										atomicAdd(big.spill_ctr + 1, 1u); /* repair picks this step */
+										slot2 = atomicAdd(todo_count, 1u);
+										todo[slot2] = j;
+										out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = 0; out.win[2u * j] = pos; out.win[2u * j + 1u] = MGL_WIN_NONE;
+									}
+									slot2 = uni(slot2);
+									if (slot2 < big.slots) { /* else: no scratch slot, the second pass sends it on to the full walk */
+										uint16_t* gik = big.ins_key + (size_t)slot2 * big.cap; uint32_t* gip = big.ins_pos + (size_t)slot2 * big.cap;
+										uint16_t* grk = big.rem_key + (size_t)slot2 * big.cap; uint32_t* grp = big.rem_pos + (size_t)slot2 * big.cap;
+										for (uint32_t i = lane; i < ch.n_ins; i += 64) { gik[i] = ch.ins_key[i]; gip[i] = ch.ins_pos[i]; }
+										for (uint32_t i = lane; i < ch.n_rem; i += 64) { grk[i] = ch.rem_key[i]; grp[i] = ch.rem_pos[i]; }
+										uint32_t* rec = big.cont + (size_t)slot2 * MGL_CONT_WORDS;
+										if (lane < jn.count) {
+											rec[48u + lane] = jn.pos[lane];
+											reinterpret_cast<mgl_pk*>(rec + 112u)[lane] = jn.old[lane];
+											reinterpret_cast<mgl_pk*>(rec + 240u)[lane] = jn.neu[lane];
+										}
+										if (lane == 0) {
+											rec[1] = j; rec[2] = pos;
+											rec[3] = nb.pos; rec[4] = nb.ctx_state; rec[5] = nb.dists[0]; rec[6] = nb.dists[1]; rec[7] = nb.dists[2]; rec[8] = nb.dists[3];
+											rec[9] = bs.pos; rec[10] = bs.ctx_state; rec[11] = bs.dists[0]; rec[12] = bs.dists[1]; rec[13] = bs.dists[2]; rec[14] = bs.dists[3];
+											rec[15] = count; rec[16] = walked; rec[17] = npicks; rec[18] = wsoft; rec[19] = taint; rec[20] = dep;
+											rec[21] = rng.n; rec[22] = guard; rec[23] = jn.count; rec[24] = ch.n_ins; rec[25] = ch.n_rem;
+											rec[26] = (pick_best ? 1u : 0u) | (second_set ? 2u : 0u);
+											rec[28] = (uint32_t)pk; rec[29] = (uint32_t)(pk >> 32);       /* the incumbent of the pick */
+											rec[30] = (uint32_t)old; rec[31] = (uint32_t)(old >> 32);     /* the packet the repair found at p */
+											rec[32] = (uint32_t)m_second; rec[33] = (uint32_t)(m_second >> 32);
+											rec[34] = (uint32_t)(uint64_t)ch.direct; rec[35] = (uint32_t)((uint64_t)ch.direct >> 32);
+											rec[0] = MGL_CONT_MAGIC; /* the reader is a later launch */
+										}
+									}
+									return;
+								}
 								resume_old = old; pick_pos = p; pick_inc = pk;
 								request_pick = true;
 								if (!BIG && lane == 0) atomicAdd(big.spill_ctr + 1, 1u); /* repair picks this step */

@@ -209,20 +209,47 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the young-slab rate and the size gates")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher of N rank processes (one per GPU) and
+        # never touches a GPU itself (torch.cuda.device_count() does not initialise the runtime); the ranks print the
+        # one JSON line.  With fewer devices than ranks (a one-GPU box) the ranks share GPU 0 and the exchange goes
+        # through the C library's host transport -- a rehearsal of the code path, and the line says so.
+        import socket
+        import subprocess
+
+        import torch
+
+        env = dict(os.environ)
+        if torch.cuda.device_count() < args.gpus:
+            env["MGL_BENCH_SHARE_GPU"] = "1"
+            env.setdefault("MGL_BENCH_BACKEND", "gloo")
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr)
     dist = None
     backend = None
+    shared_gpu = False
     if world > 1:
         import torch
         import torch.distributed as dist
 
         # rehearsal on a one-GPU box: MGL_BENCH_BACKEND=gloo MGL_BENCH_SHARE_GPU=1 runs the same code path with every
-        # rank on GPU 0 and the exchange over gloo (RCCL refuses two ranks per device)
+        # rank on GPU 0; the exchange is still the C library's (mgl_sa_exchange_best), over its host shared-memory
+        # transport instead of RCCL (which refuses two ranks per device); torch.distributed only carries barriers
         backend = os.environ.get("MGL_BENCH_BACKEND", "nccl")
         if os.environ.get("MGL_BENCH_SHARE_GPU"):
             local_rank = 0
+            shared_gpu = True
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -256,6 +283,10 @@ def main():
     comm = None
     if dist is not None and backend == "nccl":
         comm = multi_gpu.make_comm(dist, rank, world, local_rank)  # the C library's own RCCL communicator
+    elif dist is not None and shared_gpu:
+        box = [(f"/dev/shm/mgl_bench_{os.getpid()}", int.from_bytes(os.urandom(7), "little")) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = binding.Comm.shm(box[0][0], box[0][1], rank, world, local_rank)  # the C library's host transport
 
     def sync():
         if dist is not None:
@@ -302,7 +333,9 @@ def main():
         sync()
         t1 = time.perf_counter() - t1
         exchange = {"ms": t1 * 1e3, "winner_rank": winner, "winner_est_bytes": 18 + wcost / 16384, "slab_bytes_broadcast": 8 * n,
-                    "transport": "RCCL from the C library (mgl_sa_exchange_best)" if comm is not None else f"torch.distributed/{backend} through host memory",
+                    "transport": ("RCCL from the C library (mgl_sa_exchange_best)" if backend == "nccl" else
+                                  "the C library's host shared-memory transport (mgl_sa_exchange_best; ranks share one GPU: a rehearsal)") if comm is not None
+                                 else f"torch.distributed/{backend} through host memory",
                     "amortised_ms_per_step_at_10000_steps_per_exchange": t1 * 1e3 / 10000}
 
     evals, walked = st["evaluations"], st["packets_evaluated"]
@@ -367,7 +400,7 @@ def main():
                                    + (f", bucket scan capped at {props['max_bucket_scan']}" if props.get("max_bucket_scan") else "")
                                    + (f"; slab state: greedy seed ({greedy} candidates); timed steps in accept mode {accept}" if greedy else
                                       f"; slab state: after {prepare} search steps from the all-literal slab (accept mode auto); timed steps in accept mode {accept}"),
-                       "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), 1 per GPU"
+                       "chains": n_gpus, "parallelism": f"{n_gpus} independent chain(s), " + ("ALL ON ONE GPU (rehearsal of the N > 1 path, not a scaling figure)" if shared_gpu else "1 per GPU")
                                    + (", best-slab exchange timed separately" if n_gpus > 1 else "")},
             "roofline": roof,
             "final": {"current_cost": st["current_cost"], "best_cost": st["best_cost"],

@@ -104,6 +104,8 @@ typedef struct {
 	uint64_t improving_neighbours;/* evaluations that cost less than the slab they were made from */
 	uint64_t bulk_rollbacks;      /* bulk steps whose combined parse failed the after-the-fact validation and were taken back
 	                               * as a whole (the safety net of the soft window ends; never seen) */
+	uint64_t bulk_double_writes;  /* slab entries that two journals taken by one bulk step both wanted to change (detected entry
+	                               * by entry with a compare-and-swap; such a step is taken back, so it also counts above) */
 } mgl_sa_stats;
 
 /* How a step of K costed neighbours moves the chain (the reference decides after every single
@@ -158,7 +160,12 @@ int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates);
  * (linear cooling inside the epoch).  Must be below 2^40. */
 int mgl_sa_set_temperature(mgl_sa* sa, uint64_t temperature);
 int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_threshold);
-/* The modes of the steps of the last mgl_sa_run (0 single, 1 bulk), for replaying a run elsewhere. */
+/* The modes of the steps of the last mgl_sa_run (0 single, 1 bulk), for replaying a run elsewhere; of a call of more
+ * than 2^20 steps only the first 2^20 are kept.  In MGL_ACCEPT_AUTO the mode is chosen per block of 16 single (4 bulk)
+ * steps; a block carries over from one mgl_sa_run call to the next, so the sequence of modes -- and with it the
+ * trajectory -- does not depend on how a run is cut into calls; mgl_sa_begin_epoch, mgl_sa_set_slab, mgl_sa_seed_greedy
+ * and mgl_sa_set_accept_mode start a fresh block whatever came before (bulk steps first, except single steps first
+ * in an epoch that starts from the best slab). */
 int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, size_t* count);
 /* Adopt a best slab found elsewhere (another chain / GPU): replaces best slab and best cost.
  * `perplexity` must be the slab's exact cost (it is re-derived on the device and checked). */
@@ -170,11 +177,21 @@ int mgl_sa_set_best(mgl_sa* sa, const mgl_packet* packets, uint64_t perplexity);
 typedef struct mgl_comm mgl_comm;
 int mgl_comm_unique_id(uint8_t id_out[128]);
 int mgl_comm_init(mgl_comm** comm_out, const uint8_t id[128], int rank, int world, int device);
+/* The same handle over a host shared-memory file instead of RCCL (no reference counterpart either): keys and the packed
+ * slab are staged through `path` (a file on a memory-backed file system, e.g. under /dev/shm).  For chains that share one
+ * GPU -- RCCL refuses two ranks per device -- and for boxes without RCCL; mgl_sa_exchange_best runs the same protocol over
+ * it.  Rank 0 creates the file (replacing any left by an earlier run) and removes it in mgl_comm_destroy; the others wait
+ * for a file that carries this run's `nonce` and `world` (any value all ranks of one run agree on, different from run to
+ * run).  Waits -- here and in every exchange -- give up with MGL_EDEVICE after MGL_COMM_TIMEOUT_S seconds (default 600). */
+int mgl_comm_init_shm(mgl_comm** comm_out, const char* path, uint64_t nonce, int rank, int world, int device);
+/* host transport only, no device involved: the minimum over the ranks of one word each (the first half of an exchange) */
+int mgl_comm_min_u64(mgl_comm* comm, uint64_t mine, uint64_t* min_out);
 void mgl_comm_destroy(mgl_comm* comm);
 int mgl_comm_rank(const mgl_comm* comm);
 int mgl_comm_world(const mgl_comm* comm);
 /* One exchange: a single 8-byte ncclAllReduce(min) of (best_cost << 8 | rank), then ncclBroadcast of the
- * winner's best slab in its packed 8-byte device form, HBM to HBM over xGMI; chains whose own best is worse
+ * winner's best slab in its packed 8-byte device form, HBM to HBM over xGMI (the host transport stages both
+ * through its file); chains whose own best is worse
  * adopt it as packets_best (mgl_sa_begin_epoch(.., from_best) continues from it and verifies it first).
  * winner_rank / winner_cost (nullable) receive the outcome; cost 0 = no chain has a best slab yet.
  * Collective: every rank of the communicator must call it. */

@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(HERE, "_build", "libmegalania_hip.so")
-HOST_SO = os.path.join(HERE, "_build", "libmegalania_host.so")
+HOST_SO = os.environ.get("MGL_HOST_SO") or os.path.join(HERE, "_build", "libmegalania_host.so")  # the override: a sanitizer build (tests/test_sanitizers.py)
 
 # lzma_packet.h:13-17 layout
 PACKET = np.dtype([("type", "u1"), ("dist", "u4"), ("len", "u2")], align=True)
@@ -33,7 +33,7 @@ HIP_SYMBOLS = [
     "mgl_version", "mgl_last_error", "mgl_device_count", "mgl_sa_create", "mgl_sa_destroy", "mgl_sa_begin_epoch",
     "mgl_sa_set_slab", "mgl_sa_seed_greedy", "mgl_sa_set_temperature", "mgl_sa_set_accept_mode", "mgl_sa_step_modes", "mgl_sa_set_best", "mgl_sa_run", "mgl_sa_current", "mgl_sa_best", "mgl_cost_slab", "mgl_final_state", "mgl_top_k",
     "mgl_substrings", "mgl_neighbours", "mgl_rng_draw_at", "mgl_debug_dump", "mgl_debug_set",
-    "mgl_comm_unique_id", "mgl_comm_init", "mgl_comm_destroy", "mgl_comm_rank", "mgl_comm_world", "mgl_sa_exchange_best",
+    "mgl_comm_unique_id", "mgl_comm_init", "mgl_comm_init_shm", "mgl_comm_min_u64", "mgl_comm_destroy", "mgl_comm_rank", "mgl_comm_world", "mgl_sa_exchange_best",
     "mgl_sa_best_packed", "mgl_sa_adopt_best_packed",
 ]
 HOST_SYMBOLS = [
@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("gpu_ms_neighbours", C.c_double), ("gpu_ms_rebuild", C.c_double), ("neighbour_launches", C.c_uint64),
                 ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64), ("second_pass_neighbours", C.c_uint64),
                 ("bulk_steps", C.c_uint64), ("dropped_neighbours", C.c_uint64), ("improving_neighbours", C.c_uint64),
-                ("bulk_rollbacks", C.c_uint64)]
+                ("bulk_rollbacks", C.c_uint64), ("bulk_double_writes", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -117,6 +117,8 @@ def hip_lib():
         L.mgl_debug_set.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.mgl_comm_unique_id.argtypes = [C.c_void_p]
         L.mgl_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mgl_comm_init_shm.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
+        L.mgl_comm_min_u64.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.mgl_comm_destroy.argtypes = [C.c_void_p]
         L.mgl_comm_rank.argtypes = [C.c_void_p]
         L.mgl_comm_world.argtypes = [C.c_void_p]
@@ -323,7 +325,25 @@ class SA:
 
 
 class Comm:
-    """One RCCL communicator behind the C ABI (mgl_comm_*): rank 0 makes the id, every rank joins."""
+    """One communicator behind the C ABI (mgl_comm_*).  Comm(uid, rank, world, device): RCCL, rank 0 makes the id and
+    every rank joins.  Comm.shm(path, nonce, rank, world, device): the library's host shared-memory transport."""
+
+    @classmethod
+    def shm(cls, path: str, nonce: int, rank: int, world: int, device: int = 0) -> "Comm":
+        self = cls.__new__(cls)
+        self.L = hip_lib()
+        self.h = C.c_void_p()
+        if self.L.mgl_comm_init_shm(C.byref(self.h), os.fsencode(path), nonce, rank, world, device) != 0:
+            self.h = None
+            raise MglError(self.L.mgl_last_error().decode())
+        self.rank, self.world = rank, world
+        return self
+
+    def min_u64(self, mine: int) -> int:
+        out = C.c_uint64(0)
+        if self.L.mgl_comm_min_u64(self.h, mine, C.byref(out)) != 0:
+            raise MglError(self.L.mgl_last_error().decode())
+        return out.value
 
     @staticmethod
     def unique_id() -> bytes:

@@ -134,6 +134,8 @@ struct mgl_sa {
 	uint32_t bulk_threshold = 0;   /* improving neighbours per step above which a bulk step pays */
 	bool bulk_now = true;          /* AUTO: what the next block of steps runs as */
 	uint64_t bulk_hold = 0;        /* AUTO: single steps left before bulk steps are tried again (their windows were too long) */
+	uint64_t blk_done = 0;         /* AUTO: steps of the current block already run (a block carries over from one mgl_sa_run call to the next) */
+	uint64_t blk_imp0 = 0, blk_acc0 = 0; /* AUTO: the device's improving / accepted counters when the current block began */
 	BulkBuf bulk;
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
 	uint32_t force_rollbacks = 0;  /* diagnostic: treat the next so many bulk steps that took moves as failed validations */
@@ -1082,6 +1084,9 @@ extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 	if (!from_best && (rc = keep_best_before_overwrite(sa, c))) return rc;
 	c.iter = 0; c.cur_cost = 0; c.phase = phase; c.accepted_flag = 0; c.copy_best_flag = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
+	/* MGL_ACCEPT_AUTO starts every epoch the same way, whatever the previous one left behind: a fresh block, bulk steps
+	 * first from the all-literal slab (thousands of improving neighbours), single steps first from the best slab */
+	sa->bulk_now = !from_best; sa->bulk_hold = 0; sa->blk_done = 0;
 	if (from_best && base_is_best) return MGL_OK; /* main.c:73-76 would copy packets_best over itself */
 	if (snaps) {
 		SnapMeta meta[2];
@@ -1127,6 +1132,7 @@ extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
 	if ((rc = keep_best_before_overwrite(sa, c))) return rc;
+	sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; /* MGL_ACCEPT_AUTO starts over on a new slab */
 	if ((rc = import_slab(sa, packets, sa->base.v.slab))) return rc;
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
@@ -1154,6 +1160,7 @@ extern "C" int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates)
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
 	if ((rc = keep_best_before_overwrite(sa, c))) return rc;
+	sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; /* MGL_ACCEPT_AUTO starts over on a new slab */
 	hipLaunchKernelGGL(k_greedy_seed, dim3((sa->ctx.n + 255u) / 256u), dim3(256), 0, sa->stream, sa->ctx, sa->base.v.slab, candidates);
 	HIPCHK(hipGetLastError());
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
@@ -1174,6 +1181,8 @@ static hipEvent_t pool_event(mgl_sa* sa, size_t i)
 	return sa->ev_pool[i];
 }
 
+/* MGL_ACCEPT_AUTO starts over: a fresh block, bulk steps first (a new slab says nothing about the old one's windows) */
+static void auto_reset(mgl_sa* sa) { sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; }
 extern "C" int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_threshold)
 {
 	if (!sa) return fail(MGL_EINVAL, "null handle");
@@ -1181,7 +1190,7 @@ extern "C" int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_thresh
 	if (mode == MGL_ACCEPT_BULK && !(sa->incremental && sa->parallel_build)) return fail(MGL_EINVAL, "mgl_sa_set_accept_mode: bulk steps need the incremental engine and its parallel builder");
 	sa->accept_mode = mode;
 	if (bulk_threshold) sa->bulk_threshold = bulk_threshold;
-	sa->bulk_now = true; sa->bulk_hold = 0;
+	auto_reset(sa);
 	return MGL_OK;
 }
 extern "C" int mgl_sa_step_modes(mgl_sa* sa, uint8_t* modes_out, size_t cap, size_t* count)
@@ -1277,21 +1286,21 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	sa->mode_log.clear();
 	sa->la_ready = false;
 	const bool la_ok = sa->la_enabled && inc_apply && sa->split_nbr && sa->ctx.diag_stop == 0;
-	uint64_t imp_seen = before.imp_cands, acc_seen = before.accepted, last_block = 0;
 	const uint64_t rollbacks_before = sa->bulk_rollbacks;
-	bool last_bulk = false;
+	if (sa->blk_done == 0) { sa->blk_imp0 = before.imp_cands; sa->blk_acc0 = before.accepted; }
 	HIPCHK(hipEventRecord(sa->ev_begin, sa->stream));
 	for (uint64_t s = 0; s < steps;) {
 		const bool bulk = mode == MGL_ACCEPT_BULK || (mode == MGL_ACCEPT_AUTO && sa->bulk_now);
 		/* AUTO looks at the device counters between blocks of steps (one small read-back per block) */
 		/* every block ends with one small read-back: AUTO needs the counters, and the form of the regular launch
 		 * (split / one kernel) follows the device's recommendation from block to block */
-		uint64_t block = steps - s;
-		{ const uint64_t b = mode == MGL_ACCEPT_AUTO ? (bulk ? 4u : 16u) : 64u; block = block < b ? block : b; }
-		last_block = block; last_bulk = bulk;
+		/* AUTO: a block is 16 single / 4 bulk steps wherever the calls' boundaries fall (blk_done steps of it are done) */
+		const uint64_t full = mode == MGL_ACCEPT_AUTO ? (bulk ? 4u : 16u) : 64u;
+		uint64_t block = mode == MGL_ACCEPT_AUTO ? full - sa->blk_done : full;
+		if (block > steps - s) block = steps - s;
 		for (uint64_t e = s + block; s < e; s++) {
 			const bool t = s < timed_steps;
-			sa->mode_log.push_back(bulk ? 1 : 0);
+			if (sa->mode_log.size() < (1u << 20)) sa->mode_log.push_back(bulk ? 1 : 0);
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
 			/* look-ahead: this step's pick + walk may have run beside the previous step's tail, into the other buffer set */
 			const bool from_la = sa->la_ready;
@@ -1326,14 +1335,16 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			}
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 		}
-		if (s < steps && (mode == MGL_ACCEPT_AUTO || sa->adaptive)) {
+		if (mode == MGL_ACCEPT_AUTO) sa->blk_done += block;
+		const bool block_over = mode == MGL_ACCEPT_AUTO && sa->blk_done == full;
+		if (block_over || (s < steps && sa->adaptive)) {
 			Control now;
 			if ((rc = read_ctl(sa, sa->base, &now))) return rc;
 			if (now.error_flags) break;
 			if (sa->adaptive) sa->form_single = now.nbr_single != 0;
-			if (mode == MGL_ACCEPT_AUTO) {
-				auto_decide(sa, bulk, block, now.imp_cands - imp_seen, now.accepted - acc_seen);
-				imp_seen = now.imp_cands; acc_seen = now.accepted;
+			if (block_over) {
+				auto_decide(sa, bulk, full, now.imp_cands - sa->blk_imp0, now.accepted - sa->blk_acc0);
+				sa->blk_done = 0; sa->blk_imp0 = now.imp_cands; sa->blk_acc0 = now.accepted;
 			}
 		}
 	}
@@ -1341,8 +1352,6 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &after))) return rc;
 	if (sa->adaptive) sa->form_single = after.nbr_single != 0;
-	if (mode == MGL_ACCEPT_AUTO && last_block) /* the last block decides how the next call starts */
-		auto_decide(sa, last_bulk, last_block, after.imp_cands - imp_seen, after.accepted - acc_seen);
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
 		stats->steps = after.gstep - before.gstep;
@@ -1371,6 +1380,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		stats->dropped_neighbours = after.dropped - before.dropped;
 		stats->improving_neighbours = after.imp_cands - before.imp_cands;
 		stats->bulk_rollbacks = sa->bulk_rollbacks - rollbacks_before;
+		stats->bulk_double_writes = after.bulk_overlaps - before.bulk_overlaps;
 	}
 	if (after.error_flags) {
 		char buf[96];

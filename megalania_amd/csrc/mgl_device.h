@@ -100,6 +100,7 @@ struct Control {
 	uint32_t bulk_need_undo; /* bulk step: the best slab has to be restored from the new one + the undo log */
 	uint32_t la_lo, la_end;  /* window of the move the last step accepted (la_lo = MGL_POS_INF: none) */
 	uint32_t mod_lo, mod_hi; /* the last accepted move changed some context's probability before positions in (mod_lo, mod_hi] (MGL_POS_INF: to the end) */
+	uint64_t bulk_overlaps;  /* slab entries two taken journals of one bulk step both wanted to change (k_bulk_round; such a step is taken back) */
 };
 #define MGL_ERR_REBUILD_MISMATCH 1u
 #define MGL_ERR_WALK_OVERRUN 2u

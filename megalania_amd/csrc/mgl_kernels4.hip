@@ -247,8 +247,21 @@ __global__ void __launch_bounds__(256) k_bulk_round(Control* ctl, NbrOut out, Bu
 	bb.taken[at] = j;
 	atomicMin(&bb.hdr[6], (unsigned long long)key);
 	const uint32_t nd = out.ndiffs[j];
-	for (uint32_t e = 0; e < nd; e++) slab[out.dpos[(size_t)j * MGL_MAX_DIFFS + e]] = out.dnew[(size_t)j * MGL_MAX_DIFFS + e];
-	(void)ctl;
+	/* The taken journals are written in parallel and must touch disjoint entries.  The window rule is meant to guarantee
+	 * that; it is checked here, entry by entry, instead of trusted: an entry is only replaced while it still holds the value
+	 * this neighbour was evaluated against (64-bit compare-and-swap).  One that another taken journal has changed already
+	 * -- to a different packet -- would make the result depend on which of the two writes last: the step is flagged like an
+	 * invalid parse (MGL_ERR_BAD_PACKET), taken back as a whole (k_bulk_rollback restores the old values, the same for both
+	 * writers) and counted (Control::bulk_overlaps, mgl_sa_stats.bulk_double_writes; the oracle counts the same thing). */
+	for (uint32_t e = 0; e < nd; e++) {
+		const size_t k = (size_t)j * MGL_MAX_DIFFS + e;
+		const mgl_pk was = out.dold[k], neu = out.dnew[k];
+		const mgl_pk seen = (mgl_pk)atomicCAS((unsigned long long*)&slab[out.dpos[k]], (unsigned long long)was, (unsigned long long)neu);
+		if (seen != was && seen != neu) {
+			atomicOr(&ctl->error_flags, MGL_ERR_BAD_PACKET);
+			atomicAdd((unsigned long long*)&ctl->bulk_overlaps, 1ull);
+		}
+	}
 }
 
 /* bookkeeping between the selection and the rebuild */

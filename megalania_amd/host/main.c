@@ -28,7 +28,7 @@ static void usage(const char* argv0)
 	        "usage: %s [--neighbours K] [--epochs E] [--phases P] [--steps S] [--seed N]\n"
 	        "          [--lc N --lp N --pb N] [--device D] [--max-scan M]\n"
 	        "          [-o out.lzma] [--save-slab file] [--load-slab file] [--greedy-seed C] [--temperature B]\n"
-	        "          [--accept auto|single|bulk] [--chains N --rank R --comm-file PATH] filename\n"
+	        "          [--accept auto|single|bulk] [--chains N --rank R --comm-file PATH [--comm-nonce X] [--transport rccl|shm]] filename\n"
 	        "  -o           write the stream to a file instead of stdout\n"
 	        "  --save-slab  after every epoch, write the best packet slab (resumable checkpoint)\n"
 	        "  --load-slab  start from a slab written by --save-slab (same input, same lc/lp/pb)\n"
@@ -39,7 +39,10 @@ static void usage(const char* argv0)
 	        "  --chains N --rank R --comm-file PATH  one of N independent chains, one process per GPU (device = R unless\n"
 	        "               --device says otherwise): after every epoch the chains exchange their best slab over RCCL\n"
 	        "               (8-byte all-reduce + one broadcast); rank 0 creates PATH (the communicator id) and writes the\n"
-	        "               stream, the others wait for PATH\n"
+	        "               stream, the others wait for a PATH that carries the same --comm-nonce (give every run its own,\n"
+	        "               e.g. the launcher's pid: a file left by an earlier run is then never mistaken for this one's);\n"
+	        "               --transport shm stages the exchange through PATH itself (host shared memory) instead of RCCL:\n"
+	        "               for chains that share one GPU.  --save-slab: chain R > 0 writes to <file>.rankR\n"
 	        "  --accept     what a step of K neighbours takes: the best acceptable one (single), every one that is\n"
 	        "               the best of its own window (bulk), or whichever pays (auto, default)\n", argv0);
 }
@@ -61,6 +64,8 @@ int main(int argc, char** argv)
 	int accept_mode = MGL_ACCEPT_AUTO;
 	int chains = 1, rank = 0, device_given = 0;
 	const char* comm_path = NULL;
+	unsigned long long comm_nonce = 0;
+	int transport_shm = 0;
 	for (int i = 1; i < argc; i++) {
 		const char* a = argv[i];
 		const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -78,6 +83,11 @@ int main(int argc, char** argv)
 		else if (!strcmp(a, "--chains")) chains = (int)strtol(v, NULL, 0);
 		else if (!strcmp(a, "--rank")) rank = (int)strtol(v, NULL, 0);
 		else if (!strcmp(a, "--comm-file")) comm_path = v;
+		else if (!strcmp(a, "--comm-nonce")) comm_nonce = strtoull(v, NULL, 0);
+		else if (!strcmp(a, "--transport")) {
+			if (!strcmp(v, "shm")) transport_shm = 1;
+			else if (strcmp(v, "rccl") != 0) { usage(argv[0]); return -1; }
+		}
 		else if (!strcmp(a, "--max-scan")) cfg.max_bucket_scan = (uint32_t)strtoul(v, NULL, 0);
 		else if (!strcmp(a, "-o")) out_path = v;
 		else if (!strcmp(a, "--save-slab")) save_path = v;
@@ -123,23 +133,40 @@ int main(int argc, char** argv)
 		return -1;
 	}
 	mgl_comm* comm = NULL;
-	if (comm_path) { /* also with --chains 1: the same code path on a one-GPU box */
+	if (comm_path && transport_shm) {
+		if (mgl_comm_init_shm(&comm, comm_path, comm_nonce, rank, chains, cfg.device) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+	} else if (comm_path) { /* also with --chains 1: the same code path on a one-GPU box */
+		/* rendezvous file: "MGLCOMM1", u64 nonce, the 128-byte RCCL id.  Rank 0 replaces whatever an earlier run left
+		 * under the name and removes it again once every chain has joined; the others only take a file of this run */
 		uint8_t uid[128];
 		if (rank == 0) {
 			char tmp[4096];
 			snprintf(tmp, sizeof tmp, "%s.tmp", comm_path);
+			(void)unlink(comm_path);
 			FILE* f = fopen(tmp, "wb");
-			if (mgl_comm_unique_id(uid) != MGL_OK || !f || fwrite(uid, 128, 1, f) != 1 || fclose(f) != 0 || rename(tmp, comm_path) != 0) {
+			const uint64_t nonce = comm_nonce;
+			if (mgl_comm_unique_id(uid) != MGL_OK || !f || fwrite("MGLCOMM1", 8, 1, f) != 1 || fwrite(&nonce, 8, 1, f) != 1 ||
+			    fwrite(uid, 128, 1, f) != 1 || fclose(f) != 0 || rename(tmp, comm_path) != 0) {
 				fprintf(stderr, "Error: could not publish the communicator id in %s: %s\n", comm_path, mgl_last_error());
 				return -1;
 			}
 		} else {
-			FILE* f = NULL;
-			for (int tries = 0; tries < 1200 && !(f = fopen(comm_path, "rb")); tries++) usleep(100000);
-			if (!f || fread(uid, 128, 1, f) != 1) { fprintf(stderr, "Error: no communicator id in %s\n", comm_path); return -1; }
-			fclose(f);
+			const char* te = getenv("MGL_COMM_TIMEOUT_S");
+			const double limit = te && atof(te) > 0 ? atof(te) : 600.0;
+			bool got = false;
+			for (double waited = 0; !got && waited < limit; waited += 0.1) {
+				FILE* f = fopen(comm_path, "rb");
+				char magic[8];
+				uint64_t nonce = 0;
+				if (f && fread(magic, 8, 1, f) == 1 && !memcmp(magic, "MGLCOMM1", 8) && fread(&nonce, 8, 1, f) == 1 && nonce == comm_nonce &&
+				    fread(uid, 128, 1, f) == 1) got = true;
+				if (f) fclose(f);
+				if (!got) usleep(100000);
+			}
+			if (!got) { fprintf(stderr, "Error: no communicator id of this run (--comm-nonce %llu) appeared in %s\n", comm_nonce, comm_path); return -1; }
 		}
 		if (mgl_comm_init(&comm, uid, rank, chains, cfg.device) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
+		if (rank == 0) (void)unlink(comm_path); /* ncclCommInitRank returns once every rank has joined: nobody reads the file any more */
 	}
 	if (mgl_sa_set_accept_mode(sa, accept_mode, 0) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
 	mgl_packet* packets_best = (mgl_packet*)malloc(sizeof(mgl_packet) * file_size);
@@ -182,12 +209,15 @@ int main(int argc, char** argv)
 			if (save_path && st.best_cost != 0) {
 				uint64_t hdr[2] = { file_size, 0 };
 				if (mgl_sa_best(sa, packets_best, &hdr[1]) != MGL_OK) { fprintf(stderr, "Error: %s\n", mgl_last_error()); return -1; }
-				char tmp[4096];
-				snprintf(tmp, sizeof tmp, "%s.tmp", save_path);
+				/* one checkpoint per chain: chain R > 0 writes <file>.rankR (the chains run the same command line) */
+				char dst[4096], tmp[4200];
+				if (rank) snprintf(dst, sizeof dst, "%s.rank%d", save_path, rank);
+				else snprintf(dst, sizeof dst, "%s", save_path);
+				snprintf(tmp, sizeof tmp, "%s.tmp", dst);
 				FILE* f = fopen(tmp, "wb");
 				if (!f || fwrite("MGLSLAB1", 8, 1, f) != 1 || fwrite(hdr, 8, 2, f) != 2 ||
-				    fwrite(packets_best, sizeof(mgl_packet), file_size, f) != file_size || fclose(f) != 0 || rename(tmp, save_path) != 0)
-					fprintf(stderr, "warning: could not write %s\n", save_path);
+				    fwrite(packets_best, sizeof(mgl_packet), file_size, f) != file_size || fclose(f) != 0 || rename(tmp, dst) != 0)
+					fprintf(stderr, "warning: could not write %s\n", dst);
 			}
 		}
 	}

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+ORACLE_SO = os.environ.get("MGL_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "liboracle.so")  # the override: tests/test_sanitizers.py
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmegalania_ref.so")
 
 # lzma_packet.h:13-17 -- 12-byte record: type u8 @0, dist u32 @4, len u16 @8

@@ -589,7 +589,7 @@ def test_bulk_steps_do_not_depend_on_timing(monkeypatch):
     for s in range(48):
         sa_, sb_ = a.run(1), b.run(1)
         assert sa_["current_cost"] == sb_["current_cost"] and sa_["accepted"] == sb_["accepted"], s
-        assert sa_["bulk_rollbacks"] == 0
+        assert sa_["bulk_rollbacks"] == 0 and sa_["bulk_double_writes"] == 0 and sb_["bulk_double_writes"] == 0
         taken += sa_["accepted"]
     ca, cost = a.current()
     cb, _ = b.current()
@@ -617,7 +617,81 @@ def test_bulk_trajectory_vs_oracle_on_short_rep_heavy_input(seed):
     for s in range(steps):
         st = sa.run(1)
         assert st["current_cost"] == int(ref["trace"][s, 3]) and st["accepted"] == int(ref["trace"][s, 1]), s
+        assert st["bulk_double_writes"] == 0 and st["bulk_rollbacks"] == 0  # k_bulk_round's compare-and-swap saw every entry once
     cur, cost = sa.current()
     assert cost == ref["cur"] and as_list(cur) == as_list(slab)
     assert lzma.decompress(binding.emit_stream(data, sa.best()[0]), format=lzma.FORMAT_ALONE) == data
     sa.close()
+
+
+def test_auto_mode_does_not_depend_on_how_a_run_is_cut_into_calls():
+    """MGL_ACCEPT_AUTO picks single or bulk per block of 16 / 4 steps from device counters; a block carries over from one
+    mgl_sa_run call to the next, so run(1) x N, run(7) x ..., and run(N) walk the same trajectory (and begin_epoch starts the
+    same way whatever the previous epoch left behind)."""
+    data = corpus.enwik_like(40000, 0x77)
+    K, total = 1024, 84
+
+    def chain(chunks):
+        # a threshold of 150 improving neighbours per step: the bulk phase of this input ends after a few dozen steps
+        sa = binding.SA(data, accept="auto", bulk_threshold=150, neighbours_per_step=K, seed=99, iters_per_epoch=len(data))
+        modes, costs = [], []
+        for c in chunks:
+            st = sa.run(c)
+            modes += list(sa.step_modes())
+            costs.append(st["current_cost"])
+        sa.begin_epoch(1, from_best=True)
+        st = sa.run(20)
+        modes2 = list(sa.step_modes())
+        cur, cost = sa.current()
+        sa.close()
+        return modes, costs[-1], modes2, cost, cur
+
+    a = chain([total])
+    b = chain([1] * total)
+    c = chain([7] * 12)
+    assert a[0] == b[0] == c[0] and 0 < sum(a[0]) < total     # both kinds of step occur
+    assert a[1] == b[1] == c[1]
+    assert a[2] == b[2] == c[2] and a[3] == b[3] == c[3]
+    assert (a[4] == b[4]).all() and (a[4] == c[4]).all()
+
+
+def test_full_size_c3_bulk_steps_vs_oracle(monkeypatch):
+    """BASELINE configs[2] at full size in the library's default accept mode (auto: bulk steps from the all-literal slab),
+    two chains with different launch orders side by side -- the size at which two taken journals once wrote one slab entry
+    (identical chains parted after 19 bulk steps).  After the bulk steps: both chains identical step by step, no rollback, no
+    double write, device cost == the oracle's walk of the device's slab, sampled neighbours of the post-bulk slab == oracle
+    (cost and journal)."""
+    data, _ = corpus.config_input("c3")
+    n, K, seed, steps = len(data), 16384, 1673551, 24
+    monkeypatch.setenv("MGL_NO_ADAPT", "1")
+    monkeypatch.setenv("MGL_HALVES", "2")
+    a = binding.SA(data, accept="auto", neighbours_per_step=K, seed=seed)
+    monkeypatch.setenv("MGL_HALVES", "3")
+    b = binding.SA(data, accept="auto", neighbours_per_step=K, seed=seed)
+    monkeypatch.delenv("MGL_HALVES")
+    bulk = moves = 0
+    for s in range(steps):
+        sa_, sb_ = a.run(1), b.run(1)
+        assert sa_["current_cost"] == sb_["current_cost"] and sa_["accepted"] == sb_["accepted"] and sa_["evaluations"] == sb_["evaluations"], s
+        for st in (sa_, sb_):
+            assert st["bulk_rollbacks"] == 0 and st["bulk_double_writes"] == 0 and st["dropped_neighbours"] == 0, (s, st)
+        bulk += sa_["bulk_steps"]
+        moves += sa_["accepted"]
+    assert bulk >= 16 and moves > 16 * 1000          # thousands of moves per bulk step from the all-literal slab
+    ca, cost = a.current()
+    cb, cost_b = b.current()
+    assert cost == cost_b and (ca == cb).all()
+    o = Oracle(data, dict_limit=0x400000)
+    curo = ca.astype(literal_slab(1).dtype)
+    assert o.cost_slab(curo)["total"] == cost
+    costs, nd, diffs = a.neighbours(steps, want_diffs=True)
+    for j in range(0, K, 1024):                      # 16 sampled neighbours of the post-bulk slab
+        ok, c2, od = o.neighbour(curo, seed, steps, j, keep=False)
+        assert int(costs[j]) == (c2 if ok else binding.INVALID_COST), j
+        if ok:
+            got = [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in diffs[j][: nd[j]]]
+            exp = [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in od]
+            assert got == exp, j
+    assert lzma.decompress(binding.emit_stream(data, a.best()[0]), format=lzma.FORMAT_ALONE) == data
+    a.close()
+    b.close()

@@ -48,10 +48,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 DEFAULT_K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}
 PREPARE_CAP = {"c1": 400, "c2": 1500, "c3": 6000, "c4": 1500, "c5": 2000}  # steps; the bulk phase normally ends well before
 DOMINANT = ("k_neighbours2", "k_sim")  # pick, walk, re-simulation, their one-kernel form and the second pass
+SIM = "k_sim"  # the dominant kernel: the chain re-simulation (2 + 1 launches per step of the split form)
+
+
+def source_hash():
+    """What a stored rocprofv3 profile was taken of: the kernels' sources (tools/pmc_to_json.py stamps the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "megalania_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_model():
@@ -338,6 +350,16 @@ def main():
                                  else f"torch.distributed/{backend} through host memory",
                     "amortised_ms_per_step_at_10000_steps_per_exchange": t1 * 1e3 / 10000}
 
+    # the dominant kernel's algorithmic bytes, counted by the kernel itself (k_sim<true>: every chain position / event /
+    # list entry its loads ask for) over a few more steps of the same state, outside the timed region
+    counted = None
+    if rank == 0 and st.get("sim_launches"):
+        sa.debug_set(4, 1)
+        cs = sa.run(8)
+        sa.debug_set(4, 0)
+        if cs["sim_launches"]:
+            counted = dict(steps=cs["steps"], launches=cs["sim_launches"], bytes=cs["sim_bytes_counted"], evaluations=cs["evaluations"],
+                           ms=cs["gpu_ms_sim"])
     evals, walked = st["evaluations"], st["packets_evaluated"]
     if dist is not None:
         import torch
@@ -354,34 +376,57 @@ def main():
         nbr_ms = st["gpu_ms_neighbours"] / launches  # all neighbour kernels of a step, HIP events on the library's streams
         evals_per_step = st["evaluations"] / max(1, st["steps"])
         pmc, pmc_path = load_pmc(cfg)
+        sim_ms = st["gpu_ms_sim"] / st["sim_launches"] if st.get("sim_launches") else None  # HIP events on the streams k_sim runs on
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_neighbours2<*> + k_sim: the incremental neighbour evaluation (pick, window walk, chain re-simulation, or their "
-                          "one-kernel form, + second pass); the step's other launches are the decision and the accept path",
-                "avg_launch_ms": nbr_ms, "launches_timed": launches,
+                "kernel": "k_sim (chain re-simulation), the dominant kernel: one launch per slice of the step's neighbours + one over the second "
+                          "pass's list; per touched probability context a lane follows the base chain from the first change until the "
+                          "perturbed probability re-joins the base trajectory",
+                "avg_launch_ms": sim_ms, "launches_timed": st.get("sim_launches", 0),
+                "definition": "achieved = the kernel's ALGORITHMIC bytes per launch (chain positions and events and change-list entries its loads ask "
+                              "for, counted by the kernel itself in a few extra steps after the timed region) / its average launch duration measured "
+                              "live with HIP events on its streams; traffic = HBM bytes per launch from rocprofv3 FETCH_SIZE + WRITE_SIZE (raw) of "
+                              "the stored profile, null when that profile was taken of other kernel sources than the ones running",
                 "algorithmic_equiv_gbs": evals_per_step * b_eval / (nbr_ms * 1e-3) / 1e9 if nbr_ms > 0 else None,
-                "algorithmic_note": "evaluations/step x (N + 12 P) / time: what a streaming evaluator would move; the incremental "
-                                    "kernels price only the changed window, so this is not a fraction of anything",
+                "algorithmic_note": "SURVEY 8d's figure -- evaluations/step x (N + 12 P) / time of all neighbour kernels: what a streaming evaluator "
+                                    "would move; the incremental kernels price only the changed window, so this is not a fraction of anything",
                 "b_eval_bytes": b_eval, "packets_on_walk": P, "packets_walked_per_eval": walked / max(1.0, evals)}
+        if counted and sim_ms:
+            per_launch = counted["bytes"] / counted["launches"]
+            roof["algorithmic_bytes_per_launch"] = per_launch
+            roof["algorithmic_bytes_per_evaluation"] = counted["bytes"] / max(1, counted["evaluations"])
+            roof["counted_over"] = f"{counted['steps']} steps after the timed region ({counted['launches']} launches, kernel's own byte counters on)"
+            roof["achieved"] = per_launch / (sim_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        nk = {"avg_ms_per_step_live": nbr_ms, "launches_timed": launches}  # all neighbour kernels of a step together
         if pmc:
             ks = pmc["kernels"]
+            fresh = pmc.get("source_hash") == source_hash()
             dom = {k: v for k, v in ks.items() if any(k.startswith(d) for d in DOMINANT)}
-            raw = sum(v.get("hbm_bytes_raw_per_launch", 0.0) * v["launches_per_step"] for v in dom.values())
-            upper = sum(v.get("hbm_bytes_upper_per_launch", 0.0) * v["launches_per_step"] for v in dom.values())
-            prof_us = sum(v["us_per_step"] for v in dom.values())
-            if upper and nbr_ms > 0:
-                roof["traffic"] = upper
-                roof["traffic_raw"] = raw
-                roof["achieved"] = upper / (nbr_ms * 1e-3) / 1e9
-                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-                roof["frac_raw_counters"] = raw / (nbr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            sim = [v for k, v in ks.items() if k.startswith(SIM)]
             roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
-            roof["profile_us_per_step"] = prof_us
-            roof["limiter"] = {"kind": "latency / issue (dependent L2 + LDS accesses at 3-16 wavefronts per CU), not HBM",
-                               "per_kernel": {k: {c: v[c] for c in ("avg_us", "launches_per_step", "vgpr", "lds", "SQ_WAVES", "SQ_WAVE_CYCLES",
-                                                                    "SQ_BUSY_CYCLES", "wait_any_frac", "issue_stall_frac", "SQ_INSTS_VALU",
-                                                                    "SQ_INSTS_SALU", "hbm_gbs_upper") if c in v} for k, v in dom.items()}}
+            roof["traffic_profile_matches_build"] = fresh
+            if fresh and sim:
+                roof["traffic"] = sum(v.get("hbm_bytes_raw_per_launch", 0.0) * v["launches_per_step"] for v in sim) / sum(v["launches_per_step"] for v in sim)
+                roof["traffic_upper_gfx950_fetch_x2"] = sum(v.get("hbm_bytes_upper_per_launch", 0.0) * v["launches_per_step"] for v in sim) / sum(v["launches_per_step"] for v in sim)
+                roof["profile_avg_launch_ms"] = sum(v["us_per_step"] for v in sim) / sum(v["launches_per_step"] for v in sim) / 1e3
+                if sim_ms:
+                    roof["hbm_frac_raw_counters"] = roof["traffic"] / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            elif not fresh:
+                roof["traffic_note"] = "the stored profile was taken of other kernel sources (source_hash differs): no counter figure is claimed for this build"
+            if fresh:
+                raw = sum(v.get("hbm_bytes_raw_per_launch", 0.0) * v["launches_per_step"] for v in dom.values())
+                upper = sum(v.get("hbm_bytes_upper_per_launch", 0.0) * v["launches_per_step"] for v in dom.values())
+                if raw and nbr_ms > 0:
+                    nk.update(hbm_bytes_raw_per_step=raw, hbm_bytes_upper_per_step=upper, frac_raw_counters=raw / (nbr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              frac_upper_gfx950_fetch_x2=upper / (nbr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              profile_us_per_step=sum(v["us_per_step"] for v in dom.values()))
+                roof["limiter"] = {"kind": "latency / issue (dependent L2 + LDS accesses at 3-16 wavefronts per CU), not HBM",
+                                   "per_kernel": {k: {c: v[c] for c in ("avg_us", "launches_per_step", "vgpr", "lds", "SQ_WAVES", "SQ_WAVE_CYCLES",
+                                                                        "SQ_BUSY_CYCLES", "wait_any_frac", "issue_stall_frac", "SQ_INSTS_VALU",
+                                                                        "SQ_INSTS_SALU", "hbm_gbs_raw") if c in v} for k, v in dom.items()}}
         else:
             roof["traffic_source"] = f"missing: {os.path.relpath(pmc_path, ROOT)} (tools/collect_roofline.sh {cfg})"
+        roof["neighbour_kernels"] = nk
         lcpb = f"{props.get('lc', 0)}/{props.get('lp', 0)}/{props.get('pb', 0)}"
         out = {
             "metric": "SA neighbour-cost evals/s",
@@ -418,6 +463,15 @@ def main():
             out["prepare"] = {"greedy_candidates": prep.get("greedy_candidates"), "steps": prep["steps"], "seconds": t_prep, "evaluations": prep["evaluations"], "bulk_steps": prep["bulk_steps"], "bulk_rollbacks": prep["bulk_rollbacks"],
                               "moves_accepted": prep["accepted"], "est_bytes_best": 18 + prep["best_cost"] / 16384,
                               "evals_per_s": prep["evaluations"] / t_prep if t_prep > 0 else None}
+        if prep and t_prep > 0 and not greedy:
+            # what a user of the default (AUTO) mode gets over the whole run so far: the set-up phase is a search in AUTO mode
+            # from the all-literal slab (mostly bulk steps, each a parallel rebuild), the timed steps are single steps
+            out["whole_run"] = {"evals_per_s": (prep["evaluations"] + st["evaluations"]) / (t_prep + elapsed),
+                                "default_auto_mode_evals_per_s": prep["evaluations"] / t_prep,
+                                "default_auto_mode_ms_per_step": t_prep / max(1, prep["steps"]) * 1e3,
+                                "steps": prep["steps"] + st["steps"], "seconds": t_prep + elapsed,
+                                "note": "set-up search (accept mode auto, from the all-literal slab) + timed steps; `value` is the steady state "
+                                        "of a long run (single steps on the evolved slab)"}
         gates = {}
         if n <= (16 << 20):
             # correctness gates reported with the number, after the timed region: the best slab's cost

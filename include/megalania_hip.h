@@ -106,6 +106,11 @@ typedef struct {
 	                               * as a whole (the safety net of the soft window ends; never seen) */
 	uint64_t bulk_double_writes;  /* slab entries that two journals taken by one bulk step both wanted to change (detected entry
 	                               * by entry with a compare-and-swap; such a step is taken back, so it also counts above) */
+	double gpu_ms_sim;            /* sum over launches of the chain re-simulation kernel k_sim, the path's dominant kernel, each
+	                               * bracketed by HIP events on the stream it runs on (MGL_F_TIMING; split launch form only) */
+	uint64_t sim_launches;        /* the launches summed in gpu_ms_sim */
+	uint64_t sim_bytes_counted;   /* bytes of chain data (positions, events) and change lists k_sim's loads asked for, counted by
+	                               * the kernel itself while mgl_debug_set key 4 is on (its algorithmic bytes; 0 otherwise) */
 } mgl_sa_stats;
 
 /* How a step of K costed neighbours moves the chain (the reference decides after every single
@@ -241,7 +246,9 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
  * mgl_debug_set: key 0 = stop the neighbour kernels after a phase (tools/phase_cost.py), 50 =
  * stage timing in the accept path; key 1 = make the parallel builder redo every chain segment
  * serially (exercises its fallback); key 2 = shrink the first-pass change lists (a multiple of 8,
- * at most the allocated size) so that neighbours overflow into the second pass (exercises it). */
+ * at most the allocated size) so that neighbours overflow into the second pass (exercises it); key 3 = treat the
+ * next so many bulk steps that took moves as failed validations (exercises the rollback); key 4 = 1 / 0: the
+ * re-simulation kernel adds up the bytes it reads (mgl_sa_stats.sim_bytes_counted; a few percent slower). */
 int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes);
 int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value);
 /* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the

@@ -64,7 +64,8 @@ class Stats(C.Structure):
                 ("gpu_ms_neighbours", C.c_double), ("gpu_ms_rebuild", C.c_double), ("neighbour_launches", C.c_uint64),
                 ("full_rebuilds", C.c_uint64), ("fallback_neighbours", C.c_uint64), ("second_pass_neighbours", C.c_uint64),
                 ("bulk_steps", C.c_uint64), ("dropped_neighbours", C.c_uint64), ("improving_neighbours", C.c_uint64),
-                ("bulk_rollbacks", C.c_uint64), ("bulk_double_writes", C.c_uint64)]
+                ("bulk_rollbacks", C.c_uint64), ("bulk_double_writes", C.c_uint64),
+                ("gpu_ms_sim", C.c_double), ("sim_launches", C.c_uint64), ("sim_bytes_counted", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -307,6 +308,9 @@ class SA:
         self._chk(self.L.mgl_substrings(self.h, pos, max_len, _ptr(offs), _ptr(lens), cap, C.byref(cnt)))
         assert cnt.value <= cap
         return offs[: cnt.value].copy(), lens[: cnt.value].copy()
+
+    def debug_set(self, key: int, value: int):
+        self._chk(self.L.mgl_debug_set(self.h, key, value))
 
     def debug_dump(self, what: int, dtype) -> np.ndarray:
         need = C.c_size_t(0)

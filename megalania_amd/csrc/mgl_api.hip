@@ -145,6 +145,12 @@ struct mgl_sa {
 	struct NbrSet { NbrOut nbr; uint4* pickrec; uint4* pickstate; uint4* sim_hdr; uint16_t* sim_keys; uint32_t* sim_pos; uint32_t* todo; uint32_t* counts; };
 	NbrSet alt = {};
 	uint32_t sim_waves = MGL_SIM_WAVES; /* wavefronts per neighbour in the regular re-simulation launch (MGL_SIMW: 1, 2, 4, 8) */
+	/* the re-simulation kernel measured on its own (it is the path's dominant kernel): HIP events around its launches on the
+	 * streams they run on (MGL_F_TIMING), and -- when switched on, mgl_debug_set key 4 -- the bytes of chain data it reads */
+	std::vector<hipEvent_t> ev_sim_pool;
+	int64_t time_sim_step = -1;     /* >= 0: the step whose k_sim launches are bracketed by events */
+	bool count_traffic = false;
+	unsigned long long* d_traffic = nullptr; /* [0] bytes [1] spare */
 	bool la_enabled = false, la_ready = false;
 	uint8_t* d_la_mark = nullptr;
 	uint32_t* d_la_list = nullptr;
@@ -347,6 +353,15 @@ static int launch_apply(mgl_sa* sa)
 /* diagnostic switches of the launch path, read once */
 static const bool g_trace = getenv("MGL_TRACE") != nullptr, g_prof_big = getenv("MGL_PROF_BIG") != nullptr, g_big_inline_sim = getenv("MGL_BIG_INLINE_SIM") != nullptr;
 #define NBR_TRACE(name) do { if (g_trace) { fprintf(stderr, "[mgl] %s\n", name); hipError_t e_ = hipDeviceSynchronize(); if (e_ != hipSuccess) fprintf(stderr, "[mgl] %s -> %s\n", name, hipGetErrorString(e_)); } } while (0)
+static hipEvent_t sim_event(mgl_sa* sa, size_t i)
+{
+	while (sa->ev_sim_pool.size() <= i) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreate(&e) != hipSuccess) return nullptr;
+		sa->ev_sim_pool.push_back(e);
+	}
+	return sa->ev_sim_pool[i];
+}
 static mgl_sa::NbrSet cur_set(const mgl_sa* sa)
 {
 	mgl_sa::NbrSet t = { sa->nbr, sa->d_pickrec, sa->d_pickstate, sa->big.sim_hdr, sa->big.sim_keys, sa->big.sim_pos, sa->d_todo, sa->d_counts };
@@ -443,8 +458,15 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 			/* the second half's re-simulation, several wavefronts per neighbour; a neighbour with more touched contexts
 			 * than its list holds goes straight to the last resort's list (the second pass may be running by then) */
 			if (!from_lookahead) HIPCHK(hipStreamWaitEvent(sa->stream3, sa->ev_rest[h], 0));
-			hipLaunchKernelGGL(k_sim, dim3(j1 - j0), dim3(64 * sa->sim_waves), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
-			                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr); NBR_TRACE("k_sim");
+			if (sa->time_sim_step >= 0 && h < 2) HIPCHK(hipEventRecord(sim_event(sa, 6 * (size_t)sa->time_sim_step + 2 * h), sa->stream3));
+			if (sa->count_traffic)
+				hipLaunchKernelGGL(k_sim<true>, dim3(j1 - j0), dim3(64 * sa->sim_waves), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
+				                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sa->d_traffic);
+			else
+				hipLaunchKernelGGL(k_sim<false>, dim3(j1 - j0), dim3(64 * sa->sim_waves), sim_lds_regular, sa->stream3, sa->ctx, sa->b2, sa->base.ctl,
+				                   sa->nbr, sa->big, j0, j1, sa->d_todo3, sa->d_counts + 4, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
+			NBR_TRACE("k_sim");
+			if (sa->time_sim_step >= 0 && h < 2) HIPCHK(hipEventRecord(sim_event(sa, 6 * (size_t)sa->time_sim_step + 2 * h + 1), sa->stream3));
 		}
 		HIPCHK(hipEventRecord(sa->ev_sim, sa->stream3));
 		if (!from_lookahead) {
@@ -501,8 +523,15 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	if (split_now) {
 		/* the second pass handed its final re-simulations to k_sim as well (headers in sim_hdr2): a small grid over its list */
 		const uint32_t sim_lds = ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + MGL_SIM2_CAP * 16u;
-		hipLaunchKernelGGL(k_sim, dim3(256), dim3(64 * MGL_SIM_WAVES_LIST), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, big_now, 0u, K,
-		                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts); NBR_TRACE("k_sim");
+		if (sa->time_sim_step >= 0) HIPCHK(hipEventRecord(sim_event(sa, 6 * (size_t)sa->time_sim_step + 4), sa->stream));
+		if (sa->count_traffic)
+			hipLaunchKernelGGL(k_sim<true>, dim3(256), dim3(64 * MGL_SIM_WAVES_LIST), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, big_now, 0u, K,
+			                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts, sa->d_traffic);
+		else
+			hipLaunchKernelGGL(k_sim<false>, dim3(256), dim3(64 * MGL_SIM_WAVES_LIST), sim_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, big_now, 0u, K,
+			                   sa->d_todo3, sa->d_counts + 4, (const uint32_t*)sa->d_todo, (const uint32_t*)sa->d_counts, (unsigned long long*)nullptr);
+		NBR_TRACE("k_sim");
+		if (sa->time_sim_step >= 0) HIPCHK(hipEventRecord(sim_event(sa, 6 * (size_t)sa->time_sim_step + 5), sa->stream));
 		/* what k_sim (either launch) could not take: a late second pass that re-simulates inline */
 		HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_sim, 0));
 		BigScratch late = sa->big;
@@ -571,7 +600,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->big.cont);
+	dfree(sa->big.cont); dfree(sa->d_traffic);
+	for (hipEvent_t e : sa->ev_sim_pool) if (e) (void)hipEventDestroy(e);
 	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->big.sim_slot2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
 	dfree(sa->ab.tctx); dfree(sa->ab.scratch_pos); dfree(sa->ab.scratch_ev);
@@ -992,7 +1022,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			if (n > (1u << 20)) best_w = 1;
 			if (sa->pick_waves == 0 || (MGL_PICK_T_GLOBAL ? 0u : 4096u) + sa->pick_waves * sa->per_wave_pick > 160u * 1024u) sa->pick_waves = best_w;
 		}
-		HIPCHK(hipFuncSetAttribute((const void*)k_sim, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		HIPCHK(hipFuncSetAttribute((const void*)k_sim<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		HIPCHK(hipFuncSetAttribute((const void*)k_sim<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		HIPCHK(hipMalloc(&sa->d_traffic, sizeof(unsigned long long) * 2));
+		HIPCHK(hipMemset(sa->d_traffic, 0, sizeof(unsigned long long) * 2));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 		HIPCHK(hipFuncSetAttribute((const void*)k_build_end, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sa->build_lds));
 	}
@@ -1287,6 +1320,9 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	sa->la_ready = false;
 	const bool la_ok = sa->la_enabled && inc_apply && sa->split_nbr && sa->ctx.diag_stop == 0;
 	const uint64_t rollbacks_before = sa->bulk_rollbacks;
+	std::vector<uint8_t> sim_timed; /* per timed step: how many of the regular k_sim launches carry events (0: none, the one-kernel form ran) */
+	unsigned long long traffic_before[2] = { 0, 0 };
+	if (sa->count_traffic) HIPCHK(hipMemcpy(traffic_before, sa->d_traffic, sizeof traffic_before, hipMemcpyDeviceToHost));
 	if (sa->blk_done == 0) { sa->blk_imp0 = before.imp_cands; sa->blk_acc0 = before.accepted; }
 	HIPCHK(hipEventRecord(sa->ev_begin, sa->stream));
 	for (uint64_t s = 0; s < steps;) {
@@ -1310,7 +1346,11 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 				sa->alt = now;
 				sa->la_ready = false;
 			}
-			if ((rc = launch_neighbours(sa, ~0ull, (s == 0 && !from_la) || !inc_apply, from_la))) return rc;
+			sa->time_sim_step = (t && sa->split_nbr && !sa->form_single && !from_la) ? (int64_t)s : -1;
+			sim_timed.push_back(sa->time_sim_step >= 0 ? (nbr_slices(sa) < 2u ? 1 : 2) : 0);
+			rc = launch_neighbours(sa, ~0ull, (s == 0 && !from_la) || !inc_apply, from_la);
+			sa->time_sim_step = -1;
+			if (rc) return rc;
 			if (la_ok && !bulk && !sa->form_single && s + 1 < e && (rc = launch_lookahead(sa, before.gstep + s + 1, from_la))) return rc;
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
 			if (bulk) {
@@ -1373,6 +1413,20 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			stats->gpu_ms_rebuild += ms;
 		}
 		stats->neighbour_launches = timed_steps;
+		for (uint64_t s = 0; s < timed_steps && s < sim_timed.size(); s++) {
+			if (!sim_timed[s]) continue;
+			for (uint32_t h = 0; h < 3; h++) { /* the regular launches (one per slice, at most two timed) and the second pass's list */
+				if (h < 2 && h >= sim_timed[s]) continue;
+				HIPCHK(hipEventElapsedTime(&ms, sa->ev_sim_pool[6 * s + 2 * h], sa->ev_sim_pool[6 * s + 2 * h + 1]));
+				stats->gpu_ms_sim += ms;
+				stats->sim_launches++;
+			}
+		}
+		if (sa->count_traffic) {
+			unsigned long long now[2] = { 0, 0 };
+			HIPCHK(hipMemcpy(now, sa->d_traffic, sizeof now, hipMemcpyDeviceToHost));
+			stats->sim_bytes_counted = now[0] - traffic_before[0];
+		}
 		stats->full_rebuilds = after.full_rebuilds - before.full_rebuilds;
 		stats->fallback_neighbours = after.fallback_nbrs - before.fallback_nbrs;
 		stats->second_pass_neighbours = after.big_nbrs - before.big_nbrs;
@@ -1620,6 +1674,11 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 /* diagnostic knobs (tools/, tests/): key 0 = stop the neighbour kernel after phase `value`; key 1 = see below */
 extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
 {
+	if (sa && key == 4) { /* count the bytes of chain data the re-simulation kernel reads (mgl_sa_stats.sim_bytes_counted) */
+		if (!sa->d_traffic) return fail(MGL_EINVAL, "mgl_debug_set: no split neighbour evaluation on this handle");
+		sa->count_traffic = value != 0;
+		return MGL_OK;
+	}
 	if (!sa) return fail(MGL_EINVAL, "null handle");
 	if (key == 0) { sa->ctx.diag_stop = (uint32_t)value; return MGL_OK; }
 	if (key == 1) { sa->pb.force_fix = (uint32_t)value; return MGL_OK; } /* parallel builder: redo every chain segment serially */

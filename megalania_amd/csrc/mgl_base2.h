@@ -151,9 +151,12 @@ __device__ __forceinline__ mgl_wstate uni_state(mgl_wstate s)
 #ifndef MGL_LB_WIDE_ABOVE
 #define MGL_LB_WIDE_ABOVE 32768u
 #endif
-__device__ __forceinline__ uint32_t chain_lower_bound(const uint32_t* pos, uint32_t len, uint32_t x)
+/* probes (nullable): the number of chain positions read is added to it (bench.py's self-counted traffic); lo0: entries
+ * before it are known to be below x (a search that continues from a place in the chain: the pointer stays the chain's
+ * 16-byte aligned start, which the last step relies on) */
+__device__ __forceinline__ uint32_t chain_lower_bound(const uint32_t* pos, uint32_t len, uint32_t x, uint32_t* probes = nullptr, uint32_t lo0 = 0)
 {
-	uint32_t lo = 0, hi = len; /* answer in [lo, hi] */
+	uint32_t lo = lo0, hi = len; /* answer in [lo, hi] */
 	/* the top of a long chain is probed by every neighbour that touches the context (cache-resident): 8-ary steps
 	 * there, 7 independent probes per round trip.  Further down every probe is its own 64-byte fetch that nobody
 	 * else will use: 4-ary steps (3 probes) move a third of the bytes per halving of the range. */
@@ -168,6 +171,7 @@ __device__ __forceinline__ uint32_t chain_lower_bound(const uint32_t* pos, uint3
 			else if (m < nhi) nhi = m;
 		}
 		lo = nlo; hi = nhi < nlo ? nlo : nhi;
+		if (probes) *probes += 7u;
 	}
 	while (hi - lo > 8) {
 		const uint32_t step = (hi - lo) >> 2;
@@ -180,8 +184,12 @@ __device__ __forceinline__ uint32_t chain_lower_bound(const uint32_t* pos, uint3
 			else if (m < nhi) nhi = m;
 		}
 		lo = nlo; hi = nhi < nlo ? nlo : nhi;
+		if (probes) *probes += 3u;
 	}
-	/* at most 8 entries left: all of them in one round trip; the ones below x are a prefix */
+	/* at most 8 entries left: all of them in one round trip; the ones below x are a prefix.  (Read as three aligned
+	 * 16-byte units instead -- three load instructions for eight -- the re-simulation kernel spilled 14 more registers
+	 * and was no faster: c3 k_sim 226 -> 229 us per launch) */
+	if (probes) *probes += 8u;
 	uint32_t below = 0;
 #pragma unroll
 	for (uint32_t i = 0; i < 8; i++) {

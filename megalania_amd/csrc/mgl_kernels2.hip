@@ -337,8 +337,11 @@ __device__ __forceinline__ uint32_t chain_list(Changes& ch, uint32_t lane, bool*
 /* part B: this lane's share of the contexts -- uctx[first + lane], then every `stride` further on
  * (64 for a wavefront on its own; k_sim puts several wavefronts on one neighbour).  Returns the
  * lane's own sum. */
+/* traffic (nullable): the bytes of chain data this lane asked the memory system for are added to it -- 4 per position
+ * probed by a search, 48 per eight-entry chunk (positions + events), 32 per sixteen events of the re-coupling stretch:
+ * the re-simulation's algorithmic bytes, counted where they are read (bench.py's roofline block) */
 __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& ch, const uint16_t* T, uint32_t limit, uint16_t* overlay,
-                                                      uint32_t lane, uint32_t first, uint32_t stride, uint32_t nu)
+                                                      uint32_t lane, uint32_t first, uint32_t stride, uint32_t nu, uint32_t* traffic = nullptr)
 {
 	int64_t delta = 0;
 	for (uint32_t base = first; base < nu; base += stride) {
@@ -352,7 +355,9 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 		const uint32_t* cpos = b.ch_pos + b.ch_off[cx];
 		const uint16_t* cev = b.ch_ev + b.ch_off[cx];
 		const uint32_t clen = b.ch_len[cx];
-		uint32_t k = chain_lower_bound(cpos, clen, x0);
+		uint32_t probes = 0;
+		uint32_t k = chain_lower_bound(cpos, clen, x0, traffic ? &probes : nullptr);
+		if (traffic) *traffic += 12u; /* chain offset and length of this context */
 		/* eight chain entries (positions + events) per round trip, kept in registers */
 		uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa, c_ev = c_pa;
 		uint32_t c_base = 0xFFFFFFFFu;
@@ -362,6 +367,7 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 				c_pa = *reinterpret_cast<const uint4*>(cpos + c_base);
 				c_pb = *reinterpret_cast<const uint4*>(cpos + c_base + 4);
 				c_ev = *reinterpret_cast<const uint4*>(cev + c_base);
+				if (traffic) *traffic += 48u;
 			}
 		};
 		auto pos_at = [&](uint32_t kk) -> uint32_t {
@@ -408,7 +414,7 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 				const uint32_t nxt = ipos < rpos ? ipos : rpos;
 				if (nxt > bpos) {
 					if (nxt >= limit) { ended = true; break; } /* the base value holds at the limit */
-					k += chain_lower_bound(cpos + k, clen - k, nxt);
+					k = chain_lower_bound(cpos, clen, nxt, traffic ? &probes : nullptr, k);
 					chunk(k);
 					p = ev_at(k) & 0x7FFu;
 					continue;
@@ -437,6 +443,7 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 				/* may read up to 64 bytes past the sentinel: the pool is over-allocated for that */
 				const uint4 n0 = *reinterpret_cast<const uint4*>(cev + kb + 16);
 				const uint4 n1 = *reinterpret_cast<const uint4*>(cev + kb + 24);
+				if (traffic) *traffic += 32u;
 #pragma unroll
 				for (uint32_t e = 0; e < 16; e++) {
 					const uint32_t idx = kb + e;
@@ -457,6 +464,7 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 			k = kb;
 		}
 		if (ch.dbg) atomicMax(&ch.dbg[21], (unsigned long long)iters);
+		if (traffic) *traffic += 4u * probes;
 		if (overlay && (at_limit || (limit != MGL_POS_INF && cpos[k] == MGL_POS_INF))) overlay[cx] = (uint16_t)p;
 		(void)c_base;
 	}
@@ -1291,9 +1299,9 @@ struct SimShared {
 	unsigned long long* sum;
 	uint32_t* nu_many; /* [0] distinct contexts, [1] too many */
 };
-template <bool FROM_BIG>
+template <bool FROM_BIG, bool COUNT>
 __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control* ctl, const NbrOut& out, const BigScratch& big, const uint4* hdrs,
-                                        uint32_t j, uint32_t* todo, uint32_t* todo_count, const SimShared& sh)
+                                        uint32_t j, uint32_t* todo, uint32_t* todo_count, const SimShared& sh, unsigned long long* traffic_ctr)
 {
 	const uint4 hdr = hdrs[j];
 	if (hdr.x == 0xFFFFFFFFu) return; /* failed, dropped or handed on: its cost is written (uniform over the workgroup) */
@@ -1340,9 +1348,15 @@ __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control
 		return;
 	}
 	if (c.diag_stop == 41) { if (threadIdx.x == 0) out.cost[j] = sh.nu_many[0]; return; } /* diagnostic: listing only */
-	const int64_t mine = chain_sim_contexts(b, ch, sh.T, MGL_POS_INF, nullptr, lane, wid * 64u, blockDim.x, sh.nu_many[0]);
+	uint32_t traffic = 0;
+	const int64_t mine = chain_sim_contexts(b, ch, sh.T, MGL_POS_INF, nullptr, lane, wid * 64u, blockDim.x, sh.nu_many[0], COUNT ? &traffic : nullptr);
 	const uint64_t u = wave_sum64((uint64_t)mine);
 	if (lane == 0) sh.sum[wid] = u;
+	if (COUNT) {
+		/* + the change lists this workgroup brought into LDS (6 bytes per event), once per neighbour */
+		const uint64_t tb = wave_sum64((uint64_t)traffic) + (wid == 0 ? 6ull * (ch.n_ins + ch.n_rem) + 16ull : 0ull);
+		if (lane == 0) atomicAdd(traffic_ctr, (unsigned long long)tb);
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		uint64_t d = 0;
@@ -1353,8 +1367,12 @@ __device__ __forceinline__ void sim_one(const DevCtx& c, const Base2& b, Control
 }
 /* list == nullptr: the regular launch, workgroup x = neighbour j_base + x with header sim_hdr.  list != nullptr: the
  * second pass's neighbours (headers in sim_hdr2), a small grid striding over the list. */
+/* COUNT: the same kernel adding up the bytes of chain data and change lists it reads (traffic_ctr[0]) and its launches that had
+ * work (traffic_ctr[1]); bench.py runs a few steps with it after its timed region */
+template <bool COUNT>
 __global__ void __launch_bounds__(64 * MGL_SIM_WAVES_MAX, 8) k_sim(DevCtx c, Base2 b, Control* ctl, NbrOut out, BigScratch big, uint32_t j_base, uint32_t j_end,
-                                                           uint32_t* todo, uint32_t* todo_count, const uint32_t* list, const uint32_t* list_count)
+                                                           uint32_t* todo, uint32_t* todo_count, const uint32_t* list, const uint32_t* list_count,
+                                                           unsigned long long* traffic_ctr)
 {
 	if (list ? blockIdx.x >= *list_count : j_base + blockIdx.x >= j_end) return;
 	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
@@ -1371,9 +1389,9 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES_MAX, 8) k_sim(DevCtx c, Bas
 		for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
 			/* look-ahead: an entry of the speculative launch whose neighbour was evaluated again -- the second pass skipped it, its header is stale */
 			if (big.la_mark != nullptr && i < *big.la_spec_count && big.la_mark[list[i]]) continue;
-			sim_one<true>(c, b, ctl, out, big, big.sim_hdr2, list[i], todo, todo_count, sh);
+			sim_one<true, COUNT>(c, b, ctl, out, big, big.sim_hdr2, list[i], todo, todo_count, sh, traffic_ctr);
 		}
 	} else {
-		sim_one<false>(c, b, ctl, out, big, big.sim_hdr, j_base + blockIdx.x, todo, todo_count, sh);
+		sim_one<false, COUNT>(c, b, ctl, out, big, big.sim_hdr, j_base + blockIdx.x, todo, todo_count, sh, traffic_ctr);
 	}
 }

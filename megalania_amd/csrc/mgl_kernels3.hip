@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 					in_seg = false;
 					if (!pending) break;
 					/* unchanged stretch up to the next change of this context */
-					const uint32_t k2 = k + chain_lower_bound(cpos + k, len - k, nxt);
+					const uint32_t k2 = chain_lower_bound(cpos, len, nxt, nullptr, k);
 					s_piece[np].dst = dst; s_piece[np].src = k - k0; s_piece[np].count = k2 - k; s_piece[np].from_span = 0; np++;
 					dst += k2 - k;
 					k = k2;

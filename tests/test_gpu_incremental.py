@@ -363,3 +363,23 @@ def test_second_pass_takes_what_overflows_small_lists():
         sa.close()
     assert runs[0][:3] == runs[1][:3]
     assert runs[1][3] > 2 * runs[0][3] and runs[1][3] > 40 * 96 // 2  # most of the 3 840 neighbours took the second pass
+
+
+def test_counting_kernel_gives_the_same_trajectory_and_counts_bytes():
+    """mgl_debug_set key 4: the re-simulation kernel instance that adds up the bytes its loads ask for (bench.py's roofline
+    block) computes the same costs, and what it counts is plausible: at least the change lists it read and at least one chain
+    chunk per touched context."""
+    data, _ = corpus.config_input("c2")
+    a = binding.SA(data, accept="single", neighbours_per_step=2048, seed=7, timing=True)
+    b = binding.SA(data, accept="single", neighbours_per_step=2048, seed=7, timing=True)
+    a.run(30); b.run(30)
+    b.debug_set(4, 1)
+    sa_, sb_ = a.run(12), b.run(12)
+    b.debug_set(4, 0)
+    assert sa_["current_cost"] == sb_["current_cost"] and sa_["evaluations"] == sb_["evaluations"] and sa_["accepted"] == sb_["accepted"]
+    assert sa_["sim_bytes_counted"] == 0
+    if sb_["sim_launches"]:  # the split form ran (the device may have chosen the one-kernel form for some steps)
+        assert sb_["gpu_ms_sim"] > 0 and sb_["sim_bytes_counted"] > 48 * 20 * sb_["evaluations"] // 12  # > 20 contexts x one chunk per evaluation, roughly
+        assert sb_["sim_bytes_counted"] < 10**6 * sb_["evaluations"]
+    assert (a.current()[0] == b.current()[0]).all()
+    a.close(); b.close()

@@ -23,10 +23,12 @@ names = {1: "target + state_at", 2: "+ model_at (checkpoint + replay)", 31: "  t
          34: "  top-K: + runs of the deeper orders", 35: "  top-K: + rep pass", 36: "  top-K: + 16-byte run", 37: "  top-K: + 8-byte run", 38: "  top-K: + 4-byte run", 39: "  top-K: all sources, short ones filter only",
          3: "+ top-K complete / mutate", 4: "+ window walk", 41: "  re-simulation: distinct contexts listed", 42: "  re-simulation: + chain search, first chunk", 43: "  re-simulation: + merge part", 0: "+ chain_sim (everything)"}
 prev = 0.0
-for stop in (1, 2, 31, 32, 33, 34, 35, 36, 37, 39, 38, 3, 4, 41, 42, 43, 0):
+stops = (4, 41, 42, 43, 0) if os.environ.get("MGL_SIM_ONLY") else (1, 2, 31, 32, 33, 34, 35, 36, 37, 39, 38, 3, 4, 41, 42, 43, 0)
+for stop in stops:
     sa.L.mgl_debug_set(sa.h, 0, stop)
     sa.run(2)
     st = sa.run(10)
     ms = st["gpu_ms_neighbours"] / 10
-    print(f"stop={stop:2d} {names[stop]:40s} neighbour kernels {ms*1000:8.1f} us   (+{(ms-prev)*1000:8.1f})   accepted={st['accepted']}", flush=True)
+    sim = st["gpu_ms_sim"] / max(1, st["sim_launches"]) * 1000
+    print(f"stop={stop:2d} {names[stop]:40s} neighbour kernels {ms*1000:8.1f} us   (+{(ms-prev)*1000:8.1f})   k_sim avg launch {sim:7.1f} us   accepted={st['accepted']}", flush=True)
     prev = ms

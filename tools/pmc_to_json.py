@@ -87,7 +87,12 @@ for k, v in kernels.items():
     if "SQ_WAVE_CYCLES" in v and v.get("SQ_WAVE_CYCLES"):
         v["wait_any_frac"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
         v["issue_stall_frac"] = v.get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
-json.dump(dict(config=cfg, steps_averaged=steps, span_us_per_step=span_us / steps,
+import hashlib
+_h = hashlib.sha256()
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "megalania_amd", "csrc")
+for _f in sorted(os.listdir(_d)):
+    _h.update(_f.encode() + b"\0" + open(os.path.join(_d, _f), "rb").read())
+json.dump(dict(config=cfg, steps_averaged=steps, span_us_per_step=span_us / steps, source_hash=_h.hexdigest()[:16],
                note="averages over the last steps of tools/run_state.py (single steps on the evolved slab); FETCH_SIZE / WRITE_SIZE in KB; "
                     "SQ_* cycle counters count quad-cycles (MI355X_MICROARCH.md); *_upper doubles the fetch bytes (gfx950 correction) as an upper bound",
                kernels=dict(sorted(kernels.items(), key=lambda kv: -kv[1]["us_per_step"]))), open(out, "w"), indent=1)

@@ -242,7 +242,8 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
  * 11 parallel-builder totals, 12 / 13 match index (bucket offsets / positions), 14 accept-path
  * counters, 15 pick records, 16 the control block, 21 the windows (target, end) of the last costed neighbours, 22 their soft ends | dep << 31,
  * 30-35 / 40-45 / 50-55 / 60-65 positions / ranks / run starts / next byte of the exact-length orders D = 2..7,
- * 70-73 and 74-77 positions, ranks, run starts, next eight bytes of the 8- and 16-byte orders.
+ * 70-73 and 74-77 positions, ranks, run starts, next eight bytes of the 8- and 16-byte orders, 80 two u64 host counters: bulk
+ * steps whose moves were patched into the base structures at once (batch accept), and those that began so and fell back to the rebuild.
  * mgl_debug_set: key 0 = stop the neighbour kernels after a phase (tools/phase_cost.py), 50 =
  * stage timing in the accept path; key 1 = make the parallel builder redo every chain segment
  * serially (exercises its fallback); key 2 = shrink the first-pass change lists (a multiple of 8,

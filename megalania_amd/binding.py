@@ -309,6 +309,11 @@ class SA:
         assert cnt.value <= cap
         return offs[: cnt.value].copy(), lens[: cnt.value].copy()
 
+    def batch_counters(self):
+        """(bulk steps whose moves were patched into the base by the batch accept, bulk steps that began one and fell back to the rebuild)"""
+        v = self.debug_dump(80, np.uint64)
+        return int(v[0]), int(v[1])
+
     def debug_set(self, key: int, value: int):
         self._chk(self.L.mgl_debug_set(self.h, key, value))
 

@@ -6,6 +6,7 @@
 #include "mgl_kernels2.hip"
 #include "mgl_kernels3.hip"
 #include "mgl_kernels4.hip"
+#include "mgl_kernels5.hip"
 #include "mgl_pbuild.hip"
 #include "mgl_index.hip"
 #include "../../include/megalania_hip.h"
@@ -137,6 +138,9 @@ struct mgl_sa {
 	uint64_t blk_done = 0;         /* AUTO: steps of the current block already run (a block carries over from one mgl_sa_run call to the next) */
 	uint64_t blk_imp0 = 0, blk_acc0 = 0; /* AUTO: the device's improving / accepted counters when the current block began */
 	BulkBuf bulk;
+	BatchBuf batch;               /* a bulk step that took few moves patches the base instead of rebuilding it (mgl_kernels5.hip) */
+	bool batch_ok = false;
+	uint64_t batch_accepts = 0, batch_fallbacks = 0; /* bulk steps whose moves were patched in / that went to the rebuild although a batch accept began */
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
 	uint32_t force_rollbacks = 0;  /* diagnostic: treat the next so many bulk steps that took moves as failed validations */
 	uint64_t bulk_rollbacks = 0;   /* bulk steps whose combined parse failed validation and was taken back (never seen) */
@@ -342,8 +346,8 @@ static int launch_apply(mgl_sa* sa)
 		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
 		                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
 	hipLaunchKernelGGL(k_apply_chains, dim3(sa->apply_blocks), dim3(MGL_APPLY_THREADS), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->ab);
-	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0);
-	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1);
+	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 0, (const uint32_t*)nullptr);
+	hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, sa->b2, (const Control*)sa->base.ctl, sa->ab, 1, (const uint32_t*)nullptr);
 	hipLaunchKernelGGL(k_build_end, dim3(1), dim3(64), sa->build_lds, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->snapshots ? 1 : 0, sa->d_counts, sa->adaptive ? 1 : 0, sa->form_single ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
@@ -601,6 +605,11 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
 	dfree(sa->big.cont); dfree(sa->d_traffic);
+	{
+		BatchBuf& bt = sa->batch;
+		dfree(bt.hdr); dfree(bt.cl); dfree(bt.jpos); dfree(bt.jnew); dfree(bt.jold); dfree(bt.st_ikey); dfree(bt.st_rkey); dfree(bt.st_ipos);
+		dfree(bt.st_rpos); dfree(bt.ops); dfree(bt.ins_cl); dfree(bt.rem_cl); dfree(bt.ctxbits); dfree(bt.acc);
+	}
 	for (hipEvent_t e : sa->ev_sim_pool) if (e) (void)hipEventDestroy(e);
 	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->big.sim_slot2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
 	dfree(sa->ab.hdr); dfree(sa->ab.ins_key); dfree(sa->ab.rem_key); dfree(sa->ab.ins_pos); dfree(sa->ab.rem_pos);
@@ -872,14 +881,14 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			/* one workgroup per touched context plans the rewrite; the copies run as job lists */
 			sa->apply_blocks = 256;
 			ab.scratch_cap = b.pool_cap + 256u;
-			ab.span_cap = 1u << 20;
-			ab.job_cap = 1u << 18;
+			ab.span_cap = 1u << 22;
+			ab.job_cap = 1u << 20;
 			HIPCHK(hipMalloc(&ab.hdr, sizeof(uint32_t) * 16));
 			HIPCHK(hipMemset(ab.hdr, 0, sizeof(uint32_t) * 16));
-			HIPCHK(hipMalloc(&ab.ins_key, sizeof(uint16_t) * MGL_APPLY_CAP));
-			HIPCHK(hipMalloc(&ab.rem_key, sizeof(uint16_t) * MGL_APPLY_CAP));
-			HIPCHK(hipMalloc(&ab.ins_pos, sizeof(uint32_t) * MGL_APPLY_CAP));
-			HIPCHK(hipMalloc(&ab.rem_pos, sizeof(uint32_t) * MGL_APPLY_CAP));
+			HIPCHK(hipMalloc(&ab.ins_key, sizeof(uint16_t) * MGL_BATCH_ALLOC)); /* a single accept uses MGL_APPLY_CAP of it */
+			HIPCHK(hipMalloc(&ab.rem_key, sizeof(uint16_t) * MGL_BATCH_ALLOC)); /* a single accept uses MGL_APPLY_CAP of it */
+			HIPCHK(hipMalloc(&ab.ins_pos, sizeof(uint32_t) * MGL_BATCH_ALLOC)); /* a single accept uses MGL_APPLY_CAP of it */
+			HIPCHK(hipMalloc(&ab.rem_pos, sizeof(uint32_t) * MGL_BATCH_ALLOC)); /* a single accept uses MGL_APPLY_CAP of it */
 			HIPCHK(hipMalloc(&ab.tctx, sizeof(uint16_t) * 16384));
 			HIPCHK(hipMalloc(&ab.scratch_pos, sizeof(uint32_t) * (size_t)ab.scratch_cap));
 			HIPCHK(hipMalloc(&ab.scratch_ev, sizeof(uint16_t) * (size_t)ab.scratch_cap));
@@ -887,6 +896,25 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&ab.span_ev, sizeof(uint16_t) * (size_t)ab.span_cap));
 			HIPCHK(hipMalloc(&ab.jobs_b, sizeof(uint4) * (size_t)ab.job_cap));
 			HIPCHK(hipMalloc(&ab.jobs_c, sizeof(uint4) * (size_t)ab.job_cap));
+			BatchBuf& bt = sa->batch;
+			memset(&bt, 0, sizeof bt);
+			HIPCHK(hipMalloc(&bt.hdr, sizeof(uint32_t) * 16));
+			HIPCHK(hipMemset(bt.hdr, 0, sizeof(uint32_t) * 16));
+			HIPCHK(hipMalloc(&bt.cl, sizeof(uint32_t) * 8 * MGL_BATCH_MAX));
+			HIPCHK(hipMalloc(&bt.jpos, sizeof(uint32_t) * MGL_BATCH_MAX * MGL_MAX_DIFFS));
+			HIPCHK(hipMalloc(&bt.jnew, sizeof(mgl_pk) * MGL_BATCH_MAX * MGL_MAX_DIFFS));
+			HIPCHK(hipMalloc(&bt.jold, sizeof(mgl_pk) * MGL_BATCH_MAX * MGL_MAX_DIFFS));
+			HIPCHK(hipMalloc(&bt.st_ikey, sizeof(uint16_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.st_rkey, sizeof(uint16_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.st_ipos, sizeof(uint32_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.st_rpos, sizeof(uint32_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.ops, sizeof(uint4) * 2 * (size_t)MGL_BATCH_MAX * MGL_BATCH_OPCAP));
+			HIPCHK(hipMalloc(&bt.ins_cl, MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.rem_cl, MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.ctxbits, sizeof(uint32_t) * 512));
+			HIPCHK(hipMalloc(&bt.acc, sizeof(long long) * 4));
+			HIPCHK(hipMemset(bt.acc, 0, sizeof(long long) * 4));
+			sa->batch_ok = sa->incremental_apply && getenv("MGL_NO_BATCH") == nullptr;
 		}
 		{
 			/* journal + context bitmap + max(model + price tables, change lists + context list) */
@@ -1270,13 +1298,44 @@ static int launch_bulk_tail(mgl_sa* sa)
 	}
 	hipLaunchKernelGGL(k_bulk_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, a);
 	HIPCHK(hipGetLastError());
-	int rc = launch_pbuild(sa, sa->incremental);
-	if (rc) return rc;
-	/* the taken set is checked after the fact (soft window ends rest on an argument about rep distances, not on a
-	 * proof for every coincidence of values): every packet of the new parse against the input; a parse that fails is
-	 * taken back as a whole.  One small read-back per bulk step (a bulk step is a rebuild: milliseconds) */
-	{
+	int rc = MGL_OK;
+	/* A step that took few moves patches the base structures for all of them at once (mgl_kernels5.hip); every kernel of
+	 * that looks at the status word first, so a step that took none, or too many, passes through in a few microseconds. */
+	uint32_t bstat[8] = { 2u, 0, 0, 0, 0, 0, 0, 0 }; /* without the batch path: everything is the rebuild's */
+	if (sa->batch_ok) {
+		Base2& b = sa->b2;
+		hipLaunchKernelGGL(k_batch_clusters, dim3(1), dim3(256), 0, sa->stream, sa->ctx, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->batch);
+		hipLaunchKernelGGL(k_batch_walk, dim3(MGL_BATCH_MAX), dim3(64), 0, sa->stream, sa->ctx, b, sa->batch);
+		hipLaunchKernelGGL(k_batch_commit, dim3(MGL_BATCH_MAX), dim3(256), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
+		hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, sa->stream, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
+		hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, sa->stream, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
+		hipLaunchKernelGGL(k_batch_ctxlist, dim3(1), dim3(64), 0, sa->stream, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_batch_chains, dim3(sa->apply_blocks), dim3(MGL_BATCH_THREADS), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 0, (const uint32_t*)sa->batch.hdr);
+		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 1, (const uint32_t*)sa->batch.hdr);
+		hipLaunchKernelGGL(k_batch_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->batch);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(bstat, sa->batch.hdr, sizeof bstat, hipMemcpyDeviceToHost, sa->stream));
+		HIPCHK(hipStreamSynchronize(sa->stream));
+	}
+	if (bstat[0] == 3u) sa->batch_accepts++; /* the moves are in: structures patched, exact cost in Control::rebuild_cost, every rep packet of the new walk checked */
+	else if (bstat[0] != 0u) {
+		/* the rebuild's: the journals into the slab (unless the batch accept got as far as writing them: status 1 = it gave
+		 * up behind its commit), everything that hangs off the slab re-derived, the parse checked after the fact (soft window
+		 * ends rest on an argument about rep distances, not on a proof for every coincidence of values): every packet of
+		 * the new parse against the input; a parse that fails is taken back as a whole.  One small read-back per bulk
+		 * step (a bulk step of this kind is a rebuild: milliseconds) */
+		if (sa->batch_ok && bstat[0] == 1u) sa->batch_fallbacks++;
+		if (bstat[0] != 1u)
+			hipLaunchKernelGGL(k_bulk_write, dim3(64), dim3(256), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, sa->base.v.slab);
+		HIPCHK(hipGetLastError());
 		Control now;
+		if (sa->batch_ok && bstat[0] == 1u) { /* apply_failed was raised: not the rebuild's concern */
+			if ((rc = read_ctl(sa, sa->base, &now))) return rc;
+			now.apply_failed = 0;
+			if ((rc = write_ctl(sa, sa->base, &now))) return rc;
+		}
+		if ((rc = launch_pbuild(sa, sa->incremental))) return rc;
 		if ((rc = read_ctl(sa, sa->base, &now))) return rc;
 		if (sa->force_rollbacks && now.taken) { sa->force_rollbacks--; now.error_flags |= MGL_ERR_BAD_PACKET; } /* diagnostic (mgl_debug_set key 3): exercise the net */
 		if (now.error_flags & MGL_ERR_BAD_PACKET) {
@@ -1640,6 +1699,14 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 	case 7: src = b.ck_probs; sz = sizeof(uint16_t) * (size_t)b.nck * b.ck_elems; break;
 	case 8: src = b.ch_cap; sz = sizeof(uint32_t) * sa->ctx.L.total; break;
 	case 9: src = sa->d_prof; sz = sa->d_prof ? sizeof(unsigned long long) * (32 + sa->cfg.neighbours_per_step) : 0; break;
+	case 80: { /* host counters: batch accepts, batch accepts that fell back to the rebuild */
+		const uint64_t v[2] = { sa->batch_accepts, sa->batch_fallbacks };
+		*bytes = sizeof v;
+		if (cap_bytes >= sizeof v) memcpy(out, v, sizeof v);
+		return MGL_OK;
+	}
+	case 81: src = sa->batch.hdr; sz = sizeof(uint32_t) * 16; break;
+	case 82: src = sa->batch.acc; sz = sizeof(long long) * 4; break;
 	case 10: src = sa->d_counts + 8; sz = sizeof(uint32_t) * 4; break; /* of the last finished step / mgl_neighbours call */
 	case 14: src = sa->ab.hdr; sz = sa->ab.hdr ? sizeof(uint32_t) * 16 : 0; break; /* apply counters / stage cycles */
 	case 16: src = sa->base.ctl; sz = sizeof(Control); break; /* raw control block */

@@ -760,9 +760,12 @@ __global__ void __launch_bounds__(256) k_snapshot(SnapPlan p, Control* ctl, Snap
 
 /* carry out one list of copy jobs: entries (position u32 + event u16) between the chain pool, the
  * save area and the span area */
-__global__ void __launch_bounds__(256) k_apply_jobs(Base2 b, const Control* ctl, ApplyBuf ab, int pass)
+#define MGL_SPACE_SHIFT2 4u /* job kind (batch accept, mgl_kernels5.hip): in-place shift of one chunk of a stretch, slivers saved at both ends */
+/* batch_hdr: nullptr for a single accept (runs when this step accepted a move), else the batch accept's header (runs while
+ * its status is 1) */
+__global__ void __launch_bounds__(256) k_apply_jobs(Base2 b, const Control* ctl, ApplyBuf ab, int pass, const uint32_t* batch_hdr)
 {
-	if (!ctl->accepted_flag || ctl->apply_failed) return;
+	if (batch_hdr ? (batch_hdr[0] != 1u || batch_hdr[4] != 0u || ctl->apply_failed) : (!ctl->accepted_flag || ctl->apply_failed)) return;
 	const uint32_t njobs = ab.hdr[pass == 0 ? 4 : 5];
 	const uint4* jobs = pass == 0 ? ab.jobs_b : ab.jobs_c;
 	for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
@@ -785,6 +788,35 @@ __global__ void __launch_bounds__(256) k_apply_jobs(Base2 b, const Control* ctl,
 					const uint32_t si = left ? (i - (cnt - sl)) : i;
 					rp[u] = in_sliver ? ab.scratch_pos[job.y + si] : b.ch_pos[job.x + i];
 					re[u] = in_sliver ? ab.scratch_ev[job.y + si] : b.ch_ev[job.x + i];
+				}
+			}
+			__syncthreads();
+			const uint32_t to = left ? job.x - ad : job.x + ad;
+#pragma unroll
+			for (uint32_t u = 0; u < MGL_JOB_CHUNK / 256u; u++) {
+				const uint32_t i = u * 256u + threadIdx.x;
+				if (i < cnt) { b.ch_pos[to + i] = rp[u]; b.ch_ev[to + i] = re[u]; }
+			}
+			__syncthreads();
+			continue;
+		}
+		if (ss == MGL_SPACE_SHIFT2) {
+			/* entries [x, x + z) of the chain pool move by delta; their first and last `sl` entries -- all that another piece's
+			 * stores can reach before this chunk has loaded -- come from the copies pass B took (first at y, last at y + maxd) */
+			const uint32_t ad = (job.w >> 8) & 0xFFFu, cnt = job.z, maxd = job.w >> 21;
+			const bool left = (job.w >> 20) & 1u;
+			const uint32_t sl = maxd < cnt ? maxd : cnt;
+			uint32_t rp[MGL_JOB_CHUNK / 256u];
+			uint16_t re[MGL_JOB_CHUNK / 256u];
+#pragma unroll
+			for (uint32_t u = 0; u < MGL_JOB_CHUNK / 256u; u++) {
+				const uint32_t i = u * 256u + threadIdx.x;
+				rp[u] = 0; re[u] = 0;
+				if (i < cnt) {
+					const bool head = i < sl, tail = i >= cnt - sl;
+					const uint32_t si = head ? i : maxd + (i - (cnt - sl));
+					rp[u] = (head || tail) ? ab.scratch_pos[job.y + si] : b.ch_pos[job.x + i];
+					re[u] = (head || tail) ? ab.scratch_ev[job.y + si] : b.ch_ev[job.x + i];
 				}
 			}
 			__syncthreads();

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_bulk_pairs(BulkBuf bb, uint32_t K, uint
 		if (s_st[i] != 2 && s_key[i] < key && windows_conflict(s_win[i], w)) f |= s_st[i] == 1 ? 1u : 2u;
 	if (f) atomicOr(&bb.cflags[a], f);
 }
-/* second half: the verdicts of the round; the taken ones write their journals into the slab at once */
+/* second half: the verdicts of the round */
 __global__ void __launch_bounds__(256) k_bulk_round(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab, uint32_t K, uint32_t round)
 {
 	const uint32_t n = (uint32_t)bb.hdr[0];
@@ -246,20 +246,28 @@ __global__ void __launch_bounds__(256) k_bulk_round(Control* ctl, NbrOut out, Bu
 	const unsigned long long at = atomicAdd(&bb.hdr[1], 1ull);
 	bb.taken[at] = j;
 	atomicMin(&bb.hdr[6], (unsigned long long)key);
-	const uint32_t nd = out.ndiffs[j];
-	/* The taken journals are written in parallel and must touch disjoint entries.  The window rule is meant to guarantee
-	 * that; it is checked here, entry by entry, instead of trusted: an entry is only replaced while it still holds the value
-	 * this neighbour was evaluated against (64-bit compare-and-swap).  One that another taken journal has changed already
-	 * -- to a different packet -- would make the result depend on which of the two writes last: the step is flagged like an
-	 * invalid parse (MGL_ERR_BAD_PACKET), taken back as a whole (k_bulk_rollback restores the old values, the same for both
-	 * writers) and counted (Control::bulk_overlaps, mgl_sa_stats.bulk_double_writes; the oracle counts the same thing). */
-	for (uint32_t e = 0; e < nd; e++) {
-		const size_t k = (size_t)j * MGL_MAX_DIFFS + e;
-		const mgl_pk was = out.dold[k], neu = out.dnew[k];
-		const mgl_pk seen = (mgl_pk)atomicCAS((unsigned long long*)&slab[out.dpos[k]], (unsigned long long)was, (unsigned long long)neu);
-		if (seen != was && seen != neu) {
-			atomicOr(&ctl->error_flags, MGL_ERR_BAD_PACKET);
-			atomicAdd((unsigned long long*)&ctl->bulk_overlaps, 1ull);
+	(void)ctl; (void)out; (void)slab;
+}
+/* The journals of the taken neighbours into the slab, for the rebuild (a batch accept writes them itself, mgl_kernels5.hip).
+ * They are written in parallel and must touch disjoint entries.  The window rule is meant to guarantee that; it is checked
+ * here, entry by entry, instead of trusted: an entry is only replaced while it still holds the value this neighbour was
+ * evaluated against (64-bit compare-and-swap).  One that another taken journal has changed already -- to a different
+ * packet -- would make the result depend on which of the two writes last: the step is flagged like an invalid parse
+ * (MGL_ERR_BAD_PACKET), taken back as a whole (k_bulk_rollback restores the old values, the same for both writers) and
+ * counted (Control::bulk_overlaps, mgl_sa_stats.bulk_double_writes; the oracle counts the same thing). */
+__global__ void __launch_bounds__(256) k_bulk_write(Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* slab)
+{
+	const uint32_t taken = (uint32_t)bb.hdr[1];
+	for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < taken; t += gridDim.x * blockDim.x) {
+		const uint32_t j = bb.taken[t], nd = out.ndiffs[j];
+		for (uint32_t e = 0; e < nd; e++) {
+			const size_t k = (size_t)j * MGL_MAX_DIFFS + e;
+			const mgl_pk was = out.dold[k], neu = out.dnew[k];
+			const mgl_pk seen = (mgl_pk)atomicCAS((unsigned long long*)&slab[out.dpos[k]], (unsigned long long)was, (unsigned long long)neu);
+			if (seen != was && seen != neu) {
+				atomicOr(&ctl->error_flags, MGL_ERR_BAD_PACKET);
+				atomicAdd((unsigned long long*)&ctl->bulk_overlaps, 1ull);
+			}
 		}
 	}
 }

@@ -1,0 +1,719 @@
+/*
+ * mgl_kernels5.hip -- accepting SEVERAL neighbours of one step without rebuilding the base.
+ *
+ * A bulk step takes a set of mutually compatible neighbours (mgl_kernels4.hip).  Deriving every base structure again
+ * from the slab (mgl_pbuild.hip) costs 3 ms at 10 MB whether the step took five moves or five thousand.  When it took
+ * at most MGL_BATCH_MAX, the structures are patched instead, the way a single accept patches them (mgl_kernels3.hip),
+ * for all the moves at once:
+ *
+ *   k_batch_clusters  the taken neighbours in position order; those whose windows reach into each other (a neighbour
+ *                     may start behind another's soft end, before the rep distances have met again) form a cluster
+ *                     with one merged journal.  Clusters are separated by points where walk and base agree entirely.
+ *   k_batch_walk      one wavefront per cluster re-runs the two-pointer walk of the merged journal against the OLD base
+ *                     (nothing is modified while any walk is running): what changes in the bitmaps and the special-state
+ *                     records goes to an op list, the inserted / removed events to a staging area; every rep packet on
+ *                     the new walk inside the cluster is checked against the input (the window rule of the selection
+ *                     rests on an argument: here is where a wrong combination would show).
+ *   k_batch_commit    ops into the bitmaps (atomics: clusters share words) and state records, journals into the slab,
+ *                     staged events into one list in position order.  The summary levels of the special bitmap are
+ *                     re-derived afterwards (pb_levels).
+ *   k_batch_ctxlist   the touched contexts, ascending.
+ *   k_batch_chains    one workgroup per touched context.  Its events fall into groups (one per cluster that touches
+ *                     it); a thread per group re-simulates from the group's first change until the probability re-joins
+ *                     the old trajectory -- through the following groups when it has not re-joined by their first
+ *                     change, so a run's result is exact whenever its first group starts from the old trajectory, which
+ *                     is true of the first group and then of every group that follows the end of a run: the runs that
+ *                     count are found by chasing those ends.  New entries go to the span area; the chain is rewritten
+ *                     as copy jobs (stretches between runs move by the runs' accumulated length change, in place, in
+ *                     4 096-entry chunks whose first and last entries -- all that another chunk's stores can reach
+ *                     before they are read -- are saved first); the context's dense checkpoints are patched along
+ *                     every run; the exact change of the total cost is summed (new entries - replaced entries).
+ *   k_apply_jobs      (mgl_kernels3.hip) carries out the job lists.
+ *   k_batch_end       totals into Control.
+ *
+ * Anything that does not fit (more than MGL_BATCH_MAX moves, list / journal / span capacities, an invalid rep packet)
+ * leaves the step to the full rebuild: both routes produce identical structures (tests/test_gpu_incremental.py).
+ */
+#include "mgl_base2.h"
+
+#define MGL_BATCH_MAX 64u      /* taken neighbours a batch accept handles */
+#define MGL_BATCH_JCAP 512u    /* journal entries per cluster */
+#define MGL_BATCH_EVCAP 4096u  /* inserted / removed events staged per cluster */
+#define MGL_BATCH_OPCAP 2048u  /* bitmap / state-record ops per cluster */
+#define MGL_BATCH_SUB 1024u    /* events of one kind per context */
+#define MGL_BATCH_ALLOC (MGL_BATCH_MAX * MGL_BATCH_EVCAP) /* entries of the combined event lists (ApplyBuf lists are allocated this long) */
+
+struct BatchBuf {
+	uint32_t* hdr;      /* [0] status: 0 nothing to do, 1 batch accept, 2 left to the rebuild; [1] clusters; [2] inserted events,
+	                     * [3] removed events (combined lists); [4] failure seen by a kernel; [5] journal entries; [6] touched contexts */
+	uint32_t* cl;       /* per cluster, 8 words: first journal entry, journal entries, staged inserted, staged removed, ops, first target, - , - */
+	uint32_t* jpos;     /* merged journals, cluster after cluster */
+	mgl_pk* jnew;
+	mgl_pk* jold;
+	uint16_t* st_ikey; uint32_t* st_ipos; uint16_t* st_rkey; uint32_t* st_rpos; /* per cluster MGL_BATCH_EVCAP */
+	uint4* ops;         /* per cluster MGL_BATCH_OPCAP x 2: {pos, flags | count << 8, ctx_state, d0} {d1, d2, d3, 0} */
+	uint8_t* ins_cl; uint8_t* rem_cl; /* cluster of every event of the combined lists */
+	uint32_t* ctxbits;  /* 512 words: touched contexts */
+	long long* acc;     /* [0] cost change summed by k_batch_chains [1] direct-bit cost change [2] packets on the walk, change */
+};
+#define MGL_OP_ON 1u     /* position joins the walk */
+#define MGL_OP_OFF 2u    /* `count` positions from pos on leave the walk (they are not special any more either) */
+#define MGL_OP_SPEC 4u   /* position is a non-literal packet of the new walk: special bit on, state record written */
+#define MGL_OP_PLAIN 8u  /* position is a literal of the new walk: special bit off */
+
+/* ------------------------------------------------------------------ clusters */
+__global__ void __launch_bounds__(256) k_batch_clusters(DevCtx c, const Control* ctl, NbrOut out, BulkBuf bb, BatchBuf bt)
+{
+	__shared__ uint32_t s_j[MGL_BATCH_MAX], s_t[MGL_BATCH_MAX], s_e[MGL_BATCH_MAX], s_nd[MGL_BATCH_MAX], s_ord[MGL_BATCH_MAX];
+	__shared__ uint32_t s_joff[MGL_BATCH_MAX + 1];
+	__shared__ uint32_t s_ncl, s_bad;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t m = (uint32_t)bb.hdr[1];
+	if (tid == 0) {
+		s_bad = 0; s_ncl = 0;
+		bt.hdr[0] = m == 0 ? 0u : (m > MGL_BATCH_MAX ? 2u : 1u);
+		bt.hdr[1] = 0; bt.hdr[2] = 0; bt.hdr[3] = 0; bt.hdr[4] = 0; bt.hdr[5] = 0; bt.hdr[6] = 0;
+		bt.acc[0] = 0; bt.acc[1] = 0; bt.acc[2] = 0;
+	}
+	for (uint32_t i = tid; i < 512; i += blockDim.x) bt.ctxbits[i] = 0;
+	if (m == 0 || m > MGL_BATCH_MAX) return;
+	(void)ctl;
+	if (tid < m) {
+		const uint32_t j = bb.taken[tid];
+		s_j[tid] = j; s_t[tid] = out.win[2u * j]; s_e[tid] = out.win[2u * j + 1u]; s_nd[tid] = out.ndiffs[j];
+	}
+	__syncthreads();
+	/* position order (targets are distinct: two neighbours with one target conflict) */
+	if (tid < m) {
+		uint32_t r = 0;
+		for (uint32_t i = 0; i < m; i++) r += (s_t[i] < s_t[tid] || (s_t[i] == s_t[tid] && i < tid)) ? 1u : 0u;
+		s_ord[r] = tid;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t ncl = 0, reach = 0, joff = 0;
+		for (uint32_t r = 0; r < m; r++) {
+			const uint32_t i = s_ord[r];
+			s_joff[r] = joff;
+			if (s_nd[i] == 0) continue; /* a taken neighbour that changes nothing (its mutation re-made the packet that was there) */
+			if (ncl == 0 || s_t[i] >= reach) { /* walk and base agree entirely from `reach` on: a new cluster */
+				if (ncl) bt.cl[(ncl - 1u) * 8u + 1u] = joff - bt.cl[(ncl - 1u) * 8u];
+				bt.cl[ncl * 8u] = joff; bt.cl[ncl * 8u + 5u] = s_t[i];
+				ncl++;
+			}
+			joff += s_nd[i];
+			reach = s_e[i] > reach ? s_e[i] : reach;
+		}
+		s_joff[m] = joff;
+		if (ncl) bt.cl[(ncl - 1u) * 8u + 1u] = joff - bt.cl[(ncl - 1u) * 8u];
+		s_ncl = ncl;
+		for (uint32_t q = 0; q < ncl; q++) if (bt.cl[q * 8u + 1u] > MGL_BATCH_JCAP) s_bad = 1;
+	}
+	__syncthreads();
+	/* the merged journals: member after member (a member's entries all lie before the next member's target) */
+	for (uint32_t r = 0; r < m; r++) {
+		const uint32_t i = s_ord[r], j = s_j[i], nd = s_nd[i], at = s_joff[r];
+		for (uint32_t e = tid; e < nd; e += blockDim.x) {
+			const size_t k = (size_t)j * MGL_MAX_DIFFS + e;
+			bt.jpos[at + e] = out.dpos[k]; bt.jnew[at + e] = out.dnew[k]; bt.jold[at + e] = out.dold[k];
+		}
+	}
+	__syncthreads();
+	/* ... which must come out strictly ascending: two taken journals on one entry (or out of order) are the rebuild's business */
+	const uint32_t tot = s_joff[m];
+	for (uint32_t e = tid; e + 1u < tot; e += blockDim.x) if (bt.jpos[e] >= bt.jpos[e + 1u]) s_bad = 1;
+	__syncthreads();
+	if (tid == 0) {
+		bt.hdr[1] = s_ncl; bt.hdr[5] = tot;
+		if (s_bad) bt.hdr[0] = 2u;
+	}
+}
+
+/* ------------------------------------------------------------------ the walks (read-only on the base) */
+__device__ __forceinline__ void batch_op(const BatchBuf& bt, uint32_t cl, uint32_t& nops, bool& failed, uint32_t pos, uint32_t flags, uint32_t count,
+                                         const mgl_wstate& st, uint32_t lane)
+{
+	if (nops >= MGL_BATCH_OPCAP) { failed = true; return; }
+	if (lane == 0) {
+		uint4* o = bt.ops + ((size_t)cl * MGL_BATCH_OPCAP + nops) * 2u;
+		o[0] = make_uint4(pos, flags | (count << 8), st.ctx_state, st.dists[0]);
+		o[1] = make_uint4(st.dists[1], st.dists[2], st.dists[3], 0u);
+	}
+	nops++;
+}
+/* every byte of a rep packet against its source (packet_slab_neighbour.c:74-80, as k_validate does for a whole slab) */
+__device__ __forceinline__ bool batch_rep_ok(const DevCtx& c, uint32_t p, uint32_t rd, uint32_t len, uint32_t lane)
+{
+	if (rd >= p || rd >= c.dict_limit || p + len > c.n) return false;
+	const uint32_t src = p - rd - 1u;
+	bool bad = false;
+	for (uint32_t i = lane; i < len; i += 64) bad |= c.data[src + i] != c.data[p + i];
+	return __ballot(bad) == 0;
+}
+
+__global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf bt)
+{
+	__shared__ uint32_t s_jpos[MGL_BATCH_JCAP];
+	__shared__ mgl_pk s_jnew[MGL_BATCH_JCAP];
+	__shared__ uint32_t s_ctxbits[512];
+	if (bt.hdr[0] != 1u) return;
+	const uint32_t cl = blockIdx.x, lane = threadIdx.x;
+	if (cl >= bt.hdr[1]) return;
+	const uint32_t j0 = bt.cl[cl * 8u], nd = bt.cl[cl * 8u + 1u];
+	for (uint32_t i = lane; i < nd; i += 64) { s_jpos[i] = bt.jpos[j0 + i]; s_jnew[i] = bt.jnew[j0 + i]; }
+	for (uint32_t i = lane; i < 512; i += 64) s_ctxbits[i] = 0;
+	wave_sync();
+	const uint32_t t = s_jpos[0], last_j = s_jpos[nd - 1];
+	uint16_t* ikey = bt.st_ikey + (size_t)cl * MGL_BATCH_EVCAP; uint32_t* ipos = bt.st_ipos + (size_t)cl * MGL_BATCH_EVCAP;
+	uint16_t* rkey = bt.st_rkey + (size_t)cl * MGL_BATCH_EVCAP; uint32_t* rpos = bt.st_rpos + (size_t)cl * MGL_BATCH_EVCAP;
+
+	mgl_wstate nb = uni_state(base_state_at(b, t));
+	mgl_wstate bs = nb;
+	Win win; win.base = 0xFFFFFFFFu; win.pk = 0; win.byte = 0;
+	uint32_t n_ins = 0, n_rem = 0, nops = 0;
+	int32_t dpackets = 0;
+	long long ddirect = 0;
+	bool failed = false, invalid = false;
+	uint32_t ji = 0, guard = 0;
+	while (nb.pos < c.n || bs.pos < c.n) {
+		if (failed || ++guard > (1u << 18)) { failed = true; break; }
+		if (nb.pos == bs.pos) {
+			const bool same_ctx = nb.ctx_state == bs.ctx_state;
+			const bool same_d = nb.dists[0] == bs.dists[0] && nb.dists[1] == bs.dists[1] && nb.dists[2] == bs.dists[2] && nb.dists[3] == bs.dists[3];
+			if (same_ctx && same_d && nb.pos > last_j) break;
+			if (same_ctx && nb.ctx_state < 7) {
+				uint32_t s = uni(sp_find_next(b, nb.pos));
+				if (s == MGL_POS_INF || s > c.n) s = c.n;
+				while (ji < nd && s_jpos[ji] < nb.pos) ji++;
+				if (ji < nd && s_jpos[ji] < s) s = s_jpos[ji];
+				if (s > nb.pos) {
+					const uint32_t cs = lit_steps(nb.ctx_state, s - nb.pos);
+					nb.pos = bs.pos = s; nb.ctx_state = bs.ctx_state = cs;
+					continue;
+				}
+			}
+		}
+		if (nb.pos <= bs.pos && nb.pos < c.n) {
+			const uint32_t p = nb.pos;
+			win_cover(win, c, b.slab, p, lane);
+			const mgl_pk old_at_p = win_pk(win, p);
+			while (ji < nd && s_jpos[ji] < p) ji++;
+			const mgl_pk pk = (ji < nd && s_jpos[ji] == p) ? s_jnew[ji] : old_at_p;
+			const uint32_t ntype = mgl_pk_type(pk), ndist = mgl_pk_dist(pk), nlen = mgl_pk_len(pk);
+			if (ntype < MGL_LITERAL || ntype > MGL_LONG_REP || nlen == 0 || p + nlen > c.n) { invalid = true; break; }
+			const bool paired = bs.pos == p;
+			/* a rep packet codes the bytes its distance slot points at in THIS walk: checked, not assumed */
+			if (ntype == MGL_SHORT_REP || ntype == MGL_LONG_REP) {
+				if ((ntype == MGL_LONG_REP && ndist > 3u) || !batch_rep_ok(c, p, mgl_dist_at(&nb, ntype == MGL_SHORT_REP ? 0u : ndist), nlen, lane)) { invalid = true; break; }
+			}
+			bool cancelled = false;
+			if (paired && old_at_p == pk && nb.ctx_state == bs.ctx_state) {
+				cancelled = true;
+				if (ntype == MGL_LITERAL && nb.ctx_state >= 7) {
+					const uint32_t mn = nb.dists[0] < p ? c.data[p - nb.dists[0] - 1] : 0u;
+					const uint32_t mb = bs.dists[0] < p ? c.data[p - bs.dists[0] - 1] : 0u;
+					cancelled = mn == mb;
+				}
+			}
+			mgl_plan npl, bpl;
+			uint32_t btype = 0, bdist = 0, blen = 0;
+			if (paired) { btype = mgl_pk_type(old_at_p); bdist = mgl_pk_dist(old_at_p); blen = mgl_pk_len(old_at_p); }
+			if (!cancelled) {
+				plan_at(c, nb, ntype, ndist, nlen, win_byte(win, p), npl);
+				if (paired) plan_at(c, bs, btype, bdist, blen, win_byte(win, p), bpl);
+			}
+			/* p is on the new walk; special iff not a literal, with the state before it */
+			batch_op(bt, cl, nops, failed, p, (paired ? 0u : MGL_OP_ON) | (ntype != MGL_LITERAL ? MGL_OP_SPEC : MGL_OP_PLAIN), 1u, nb, lane);
+			if (!cancelled) {
+				if (n_ins + npl.nev > MGL_BATCH_EVCAP || (paired && n_rem + bpl.nev > MGL_BATCH_EVCAP)) { failed = true; break; }
+				if (lane < npl.nev) {
+					uint32_t ctx, bit;
+					mgl_plan_event(&npl, lane, &ctx, &bit);
+					ikey[n_ins + lane] = (uint16_t)(ctx | (bit << 15));
+					ipos[n_ins + lane] = p;
+					atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+				}
+				n_ins += npl.nev;
+				ddirect += (long long)((uint64_t)npl.ndirect << 11);
+				if (paired) {
+					if (lane < bpl.nev) {
+						uint32_t ctx, bit;
+						mgl_plan_event(&bpl, lane, &ctx, &bit);
+						rkey[n_rem + lane] = (uint16_t)ctx;
+						rpos[n_rem + lane] = p;
+						atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+					}
+					n_rem += bpl.nev;
+					ddirect -= (long long)((uint64_t)bpl.ndirect << 11);
+				}
+			}
+			dpackets += paired ? 0 : 1;
+			if (paired) mgl_advance(&bs, btype, bdist, blen);
+			mgl_advance(&nb, ntype, ndist, nlen);
+		} else {
+			/* an old packet that is not on the new walk any more */
+			const uint32_t q = bs.pos;
+			win_cover(win, c, b.slab, q, lane);
+			if (bs.ctx_state < 7u) {
+				const uint32_t o = q - win.base;
+				const unsigned long long lit = __ballot(mgl_pk_type(win.pk) == MGL_LITERAL) >> o;
+				uint32_t run = ~lit == 0ull ? 64u : (uint32_t)__ffsll((long long)~lit) - 1u;
+				const uint32_t limit = (nb.pos < c.n ? nb.pos : c.n) - q;
+				run = run < 64u - o ? run : 64u - o;
+				run = run < limit ? run : limit;
+				if (run >= 2u) {
+					const uint32_t take = run < 7u ? run : 7u;
+					if (n_rem + 9u * take > MGL_BATCH_EVCAP) { failed = true; break; }
+					const uint32_t i = lane / 9u, slot = lane - i * 9u, p = q + i;
+					const bool active = i < take;
+					const uint32_t byte = (uint32_t)__shfl((int)win.byte, (int)((p - win.base) & 63u), 64);
+					uint32_t prev_byte = 0;
+					if (c.L.lc > 0) {
+						const uint32_t wprev = (uint32_t)__shfl((int)win.byte, (int)((p - 1u - win.base) & 63u), 64);
+						prev_byte = p == 0 ? 0u : (p - 1u >= win.base ? wprev : (uint32_t)c.data[p - 1u]);
+					}
+					mgl_wstate sv = bs;
+					sv.pos = p; sv.ctx_state = lit_steps(bs.ctx_state, i);
+					mgl_plan pl;
+					mgl_plan_packet(&c.L, &sv, MGL_LITERAL, 0, 1, byte, 0, prev_byte, &pl);
+					if (!__ballot(active && pl.nev != 9u)) {
+						if (active) {
+							uint32_t ctx, bit;
+							mgl_plan_event(&pl, slot, &ctx, &bit);
+							rkey[n_rem + i * 9u + slot] = (uint16_t)ctx;
+							rpos[n_rem + i * 9u + slot] = p;
+							atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+						}
+						n_rem += 9u * take;
+						batch_op(bt, cl, nops, failed, q, MGL_OP_OFF, take, bs, lane);
+						dpackets -= (int32_t)take;
+						bs.pos += take; bs.ctx_state = lit_steps(bs.ctx_state, take);
+						continue;
+					}
+				}
+			}
+			const mgl_pk bpk = win_pk(win, q);
+			const uint32_t btype = mgl_pk_type(bpk), bdist = mgl_pk_dist(bpk), blen = mgl_pk_len(bpk);
+			mgl_plan bpl;
+			plan_at(c, bs, btype, bdist, blen, win_byte(win, q), bpl);
+			if (n_rem + bpl.nev > MGL_BATCH_EVCAP) { failed = true; break; }
+			if (lane < bpl.nev) {
+				uint32_t ctx, bit;
+				mgl_plan_event(&bpl, lane, &ctx, &bit);
+				rkey[n_rem + lane] = (uint16_t)ctx;
+				rpos[n_rem + lane] = q;
+				atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
+			}
+			n_rem += bpl.nev;
+			ddirect -= (long long)((uint64_t)bpl.ndirect << 11);
+			batch_op(bt, cl, nops, failed, q, MGL_OP_OFF, 1u, bs, lane);
+			dpackets -= 1;
+			mgl_advance(&bs, btype, bdist, blen);
+		}
+	}
+	wave_sync();
+	for (uint32_t i = lane; i < 512; i += 64) if (s_ctxbits[i]) atomicOr(&bt.ctxbits[i], s_ctxbits[i]);
+	if (lane == 0) {
+		bt.cl[cl * 8u + 2u] = n_ins; bt.cl[cl * 8u + 3u] = n_rem; bt.cl[cl * 8u + 4u] = nops;
+		if (failed || invalid) atomicOr(&bt.hdr[4], invalid ? 2u : 1u);
+		atomicAdd((unsigned long long*)&bt.acc[1], (unsigned long long)ddirect);
+		atomicAdd((unsigned long long*)&bt.acc[2], (unsigned long long)(long long)dpackets);
+	}
+}
+
+/* ------------------------------------------------------------------ commit: every walk has finished, nothing reads the old base any more */
+__global__ void __launch_bounds__(256) k_batch_commit(DevCtx c, Base2 b, Control* ctl, BatchBuf bt, ApplyBuf ab)
+{
+	if (bt.hdr[0] != 1u) return;
+	if (bt.hdr[4]) { if (blockIdx.x == 0 && threadIdx.x == 0) bt.hdr[0] = 2u; return; } /* a walk gave up: nothing has been touched, the rebuild takes the step */
+	const uint32_t cl = blockIdx.x, tid = threadIdx.x, ncl = bt.hdr[1];
+	if (cl >= ncl) return;
+	(void)c; (void)ctl;
+	/* this cluster's place in the combined lists: clusters are in position order */
+	uint32_t ioff = 0, roff = 0;
+	for (uint32_t q = 0; q < cl; q++) { ioff += bt.cl[q * 8u + 2u]; roff += bt.cl[q * 8u + 3u]; }
+	const uint32_t n_ins = bt.cl[cl * 8u + 2u], n_rem = bt.cl[cl * 8u + 3u], nops = bt.cl[cl * 8u + 4u];
+	if (cl == ncl - 1u && tid == 0) { bt.hdr[2] = ioff + n_ins; bt.hdr[3] = roff + n_rem; }
+	const size_t sb = (size_t)cl * MGL_BATCH_EVCAP;
+	for (uint32_t e = tid; e < n_ins; e += blockDim.x) { ab.ins_key[ioff + e] = bt.st_ikey[sb + e]; ab.ins_pos[ioff + e] = bt.st_ipos[sb + e]; bt.ins_cl[ioff + e] = (uint8_t)cl; }
+	for (uint32_t e = tid; e < n_rem; e += blockDim.x) { ab.rem_key[roff + e] = bt.st_rkey[sb + e]; ab.rem_pos[roff + e] = bt.st_rpos[sb + e]; bt.rem_cl[roff + e] = (uint8_t)cl; }
+	/* bitmaps and state records */
+	for (uint32_t o = tid; o < nops; o += blockDim.x) {
+		const uint4 a = bt.ops[((size_t)cl * MGL_BATCH_OPCAP + o) * 2u], d = bt.ops[((size_t)cl * MGL_BATCH_OPCAP + o) * 2u + 1u];
+		const uint32_t pos = a.x, flags = a.y & 0xFFu, count = a.y >> 8;
+		const uint32_t w = pos >> 6;
+		if (flags & MGL_OP_OFF) {
+			/* `count` consecutive positions (at most seven, inside one window of 64) leave the walk */
+			const unsigned long long mask = ((count >= 64u ? ~0ull : ((1ull << count) - 1ull))) << (pos & 63u);
+			atomicAnd((unsigned long long*)&b.onwalk[w], ~mask);
+			atomicAnd((unsigned long long*)&b.sp0[w], ~mask);
+			continue;
+		}
+		const unsigned long long bit = 1ull << (pos & 63u);
+		if (flags & MGL_OP_ON) atomicOr((unsigned long long*)&b.onwalk[w], bit);
+		if (flags & MGL_OP_SPEC) {
+			atomicOr((unsigned long long*)&b.sp0[w], bit);
+			uint32_t* r = b.sp_state + (size_t)pos * 8;
+			r[0] = a.z; r[1] = a.w; r[2] = d.x; r[3] = d.y; r[4] = d.z; r[5] = 0; r[6] = 0; r[7] = 0;
+		} else if (flags & MGL_OP_PLAIN) {
+			atomicAnd((unsigned long long*)&b.sp0[w], ~bit);
+		}
+	}
+	/* the journal goes into the slab (main.c keeps the mutated slab on accept) */
+	const uint32_t j0 = bt.cl[cl * 8u], nd = bt.cl[cl * 8u + 1u];
+	for (uint32_t e = tid; e < nd; e += blockDim.x) b.slab[bt.jpos[j0 + e]] = bt.jnew[j0 + e];
+}
+
+/* touched contexts, ascending (one wavefront) */
+__global__ void __launch_bounds__(64) k_batch_ctxlist(BatchBuf bt, ApplyBuf ab)
+{
+	if (bt.hdr[0] != 1u) return;
+	const uint32_t lane = threadIdx.x;
+	uint32_t nt = 0;
+	for (uint32_t wbase = 0; wbase < 512; wbase += 64) {
+		const uint32_t word = bt.ctxbits[wbase + lane];
+		const uint32_t cntl = (uint32_t)__popc(word);
+		uint32_t incl = cntl;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t tmp = (uint32_t)__shfl_up((int)incl, o, 64);
+			if ((int)lane >= o) incl += tmp;
+		}
+		uint32_t at = nt + incl - cntl;
+		uint32_t wv = word;
+		while (wv) {
+			const uint32_t bit = (uint32_t)__ffs((int)wv) - 1u;
+			ab.tctx[at++] = (uint16_t)(((wbase + lane) << 5) + bit);
+			wv &= wv - 1u;
+		}
+		nt += (uint32_t)__shfl((int)incl, 63, 64);
+	}
+	if (lane == 0) {
+		bt.hdr[6] = nt;
+		ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0; /* job / span / scratch cursors of k_apply_jobs' lists */
+	}
+}
+
+/* ------------------------------------------------------------------ chains */
+#define MGL_BATCH_THREADS 256u
+
+struct RunOut {
+	uint32_t k_start, k_end; /* old entries [k_start, k_end) are replaced */
+	uint32_t ns;             /* by this many new entries */
+	uint32_t last_group;     /* last group whose events the run consumed */
+	uint32_t lo, hi;         /* the trajectory differs for positions in (lo, hi] (hi = MGL_POS_INF: to the end of the file) */
+	uint32_t end_p;          /* probability after the run's last new entry */
+	uint32_t uncoupled;      /* ran into the sentinel without re-joining: the sentinel's value changes */
+	long long dcost;
+};
+
+/* One run: from group g's first change through every following change that comes before the probability has re-joined the
+ * old trajectory.  WRITE = false: sizes and cost only.  WRITE = true: the new entries to span_pos / span_ev from `at` on. */
+template <bool WRITE>
+__device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t* cev, uint32_t len, const uint16_t* T,
+                                            const uint32_t* s_ipos, const uint16_t* s_ibit, const uint8_t* s_icl, uint32_t ni,
+                                            const uint32_t* s_rpos, const uint8_t* s_rcl, uint32_t nr,
+                                            uint32_t ii, uint32_t ri, const uint8_t* s_gcl, uint32_t g,
+                                            uint32_t* span_pos, uint16_t* span_ev, uint32_t at)
+{
+	RunOut r;
+	uint32_t ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF, rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
+	const uint32_t x0 = ipos < rpos ? ipos : rpos;
+	uint32_t k = chain_lower_bound(cpos, len, x0);
+	r.k_start = k; r.lo = x0; r.uncoupled = 0; r.hi = MGL_POS_INF;
+	/* eight chain entries (positions + events) per round trip, kept in registers (as in chain_sim_contexts: chains start
+	 * 32-byte aligned, the pool is over-allocated past its end) */
+	uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa, c_ev = c_pa;
+	uint32_t c_base = 0xFFFFFFFFu;
+	auto chunk = [&](uint32_t kk) {
+		if ((kk & ~7u) != c_base) {
+			c_base = kk & ~7u;
+			c_pa = *reinterpret_cast<const uint4*>(cpos + c_base);
+			c_pb = *reinterpret_cast<const uint4*>(cpos + c_base + 4);
+			c_ev = *reinterpret_cast<const uint4*>(cev + c_base);
+		}
+	};
+	auto pos_at = [&](uint32_t kk) -> uint32_t {
+		const uint32_t e = kk & 7u;
+		return e == 0 ? c_pa.x : e == 1 ? c_pa.y : e == 2 ? c_pa.z : e == 3 ? c_pa.w : e == 4 ? c_pb.x : e == 5 ? c_pb.y : e == 6 ? c_pb.z : c_pb.w;
+	};
+	auto ev_at = [&](uint32_t kk) -> uint32_t {
+		const uint32_t e = kk & 7u;
+		const uint32_t wd = e < 2 ? c_ev.x : e < 4 ? c_ev.y : e < 6 ? c_ev.z : c_ev.w;
+		return (wd >> ((e & 1u) * 16u)) & 0xFFFFu;
+	};
+	chunk(k);
+	uint32_t p = ev_at(k) & 0x7FFu;
+	uint32_t last_cl = s_gcl[g];
+	long long dc = 0;
+	uint32_t ns = 0;
+	for (;;) {
+		chunk(k);
+		const uint32_t bpos = k > len ? MGL_POS_INF : pos_at(k); /* entry `len` is the sentinel (position = infinity) */
+		if (ipos < bpos) { /* an inserted event comes first */
+			const uint32_t bit = s_ibit[ii];
+			last_cl = s_icl[ii];
+			if (WRITE) { span_pos[at + ns] = ipos; span_ev[at + ns] = (uint16_t)((bit << 15) | p); }
+			ns++;
+			dc += T[bit ? 2048u - p : p];
+			p = mgl_prob_update(p, bit);
+			ii++;
+			ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF;
+			continue;
+		}
+		if (bpos == MGL_POS_INF) { r.uncoupled = 1; break; } /* the sentinel: the final probability changes */
+		const uint32_t ev = ev_at(k);
+		const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+		const uint32_t nxt = ipos < rpos ? ipos : rpos;
+		if (p == bp && nxt > bpos) {
+			/* re-joined at old entry k (which stays), nothing changes at it.  The run ends here -- unless the context's next
+			 * change belongs to the cluster the run is in: a cluster's events in one context can come in several bunches
+			 * (a match at 246 behind literals re-priced up to 243), and a group has one run; the entries in between are
+			 * written again as they are (same probability: no cost change) */
+			const uint32_t nxt_cl = nxt == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
+			if (nxt_cl != last_cl) { r.hi = bpos; break; }
+		}
+		dc -= T[bb ? 2048u - bp : bp];
+		if (rpos == bpos) { /* the old entry goes away */
+			last_cl = s_rcl[ri];
+			ri++;
+			rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
+		} else { /* it stays, priced at the new probability */
+			if (WRITE) { span_pos[at + ns] = bpos; span_ev[at + ns] = (uint16_t)((bb << 15) | p); }
+			ns++;
+			dc += T[bb ? 2048u - p : p];
+			p = mgl_prob_update(p, bb);
+		}
+		k++;
+	}
+	r.k_end = k; r.ns = ns; r.end_p = p; r.dcost = dc;
+	/* the last group consumed: the group of the last event taken (groups are in cluster order, as the events are) */
+	uint32_t lg = g;
+	while (s_gcl[lg] != last_cl) lg++;
+	r.last_group = lg;
+	(void)c_base;
+	return r;
+}
+
+__global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Base2 b, Control* ctl, BatchBuf bt, ApplyBuf ab)
+{
+	__shared__ uint16_t T[2048];
+	__shared__ uint32_t s_ipos[MGL_BATCH_SUB], s_rpos[MGL_BATCH_SUB];
+	__shared__ uint16_t s_ibit[MGL_BATCH_SUB];
+	__shared__ uint8_t s_icl[MGL_BATCH_SUB], s_rcl[MGL_BATCH_SUB];
+	__shared__ uint32_t s_wcount[MGL_BATCH_THREADS / 64];
+	/* groups (one per cluster that touches the context, ascending) and the runs that start at them */
+	__shared__ uint8_t s_gcl[MGL_BATCH_MAX + 1];
+	__shared__ uint32_t s_gi[MGL_BATCH_MAX + 1], s_gr[MGL_BATCH_MAX + 1]; /* first inserted / removed event of the group */
+	__shared__ uint32_t s_clfirst_i[MGL_BATCH_MAX], s_clfirst_r[MGL_BATCH_MAX];
+	__shared__ RunOut s_run[MGL_BATCH_MAX];
+	__shared__ uint32_t s_hlist[MGL_BATCH_MAX], s_hspan[MGL_BATCH_MAX + 1];
+	__shared__ int32_t s_hdelta[MGL_BATCH_MAX + 1]; /* length change accumulated up to and including head h */
+	__shared__ uint32_t s_ni, s_nr, s_ng, s_nh, s_fail, s_span_base, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
+	if (bt.hdr[0] != 1u || bt.hdr[4]) return;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+	for (uint32_t i = tid; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	const uint32_t n_ins = bt.hdr[2], n_rem = bt.hdr[3], nt = bt.hdr[6], ncl = bt.hdr[1];
+	long long my_cost = 0; /* thread 0 sums the context's runs */
+	for (uint32_t ti = blockIdx.x; ti < nt; ti += gridDim.x) {
+		const uint32_t cx = ab.tctx[ti];
+		__syncthreads();
+		if (tid == 0) { s_ni = 0; s_nr = 0; s_fail = 0; }
+		for (uint32_t i = tid; i < MGL_BATCH_MAX; i += blockDim.x) { s_clfirst_i[i] = 0xFFFFFFFFu; s_clfirst_r[i] = 0xFFFFFFFFu; }
+		__syncthreads();
+		/* ---- 1. this context's events, order (= position order) preserved */
+		for (int pass = 0; pass < 2; pass++) {
+			const uint32_t m = pass == 0 ? n_ins : n_rem;
+			for (uint32_t base = 0; base < m; base += MGL_BATCH_THREADS) {
+				const uint32_t e = base + tid;
+				bool hit = false;
+				uint32_t key = 0, pos = 0, ecl = 0;
+				if (e < m) {
+					key = pass == 0 ? ab.ins_key[e] : ab.rem_key[e];
+					hit = (key & 0x7FFFu) == cx;
+					if (hit) { pos = pass == 0 ? ab.ins_pos[e] : ab.rem_pos[e]; ecl = pass == 0 ? bt.ins_cl[e] : bt.rem_cl[e]; }
+				}
+				const unsigned long long mask = __ballot(hit);
+				if (lane == 0) s_wcount[wid] = (uint32_t)__popcll(mask);
+				__syncthreads();
+				uint32_t before = pass == 0 ? s_ni : s_nr;
+				for (uint32_t w = 0; w < wid; w++) before += s_wcount[w];
+				const uint32_t idx = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+				if (hit) {
+					if (idx < MGL_BATCH_SUB) {
+						if (pass == 0) { s_ipos[idx] = pos; s_ibit[idx] = (uint16_t)(key >> 15); s_icl[idx] = (uint8_t)ecl; atomicMin(&s_clfirst_i[ecl], idx); }
+						else { s_rpos[idx] = pos; s_rcl[idx] = (uint8_t)ecl; atomicMin(&s_clfirst_r[ecl], idx); }
+					} else s_fail = 1;
+				}
+				__syncthreads();
+				if (tid == 0) {
+					uint32_t tot = 0;
+					for (uint32_t w = 0; w < MGL_BATCH_THREADS / 64; w++) tot += s_wcount[w];
+					if (pass == 0) s_ni += tot; else s_nr += tot;
+				}
+				__syncthreads();
+			}
+		}
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		/* ---- 2. groups: the clusters that touch this context, ascending; where each one's events begin in the two lists */
+		if (tid == 0) {
+			uint32_t ng = 0, ci = 0, cr = 0;
+			for (uint32_t q = 0; q < ncl; q++) {
+				const bool hi = s_clfirst_i[q] != 0xFFFFFFFFu, hr = s_clfirst_r[q] != 0xFFFFFFFFu;
+				if (!hi && !hr) continue;
+				if (hi) ci = s_clfirst_i[q];
+				if (hr) cr = s_clfirst_r[q];
+				/* a cluster without inserted (removed) events starts where the next cluster's begin */
+				s_gcl[ng] = (uint8_t)q; s_gi[ng] = hi ? ci : 0xFFFFFFFFu; s_gr[ng] = hr ? cr : 0xFFFFFFFFu;
+				ng++;
+			}
+			/* fill the gaps backwards: first event at or after the group's range in each list */
+			uint32_t nxi = s_ni, nxr = s_nr;
+			for (uint32_t g = ng; g-- > 0;) {
+				if (s_gi[g] == 0xFFFFFFFFu) s_gi[g] = nxi; else nxi = s_gi[g];
+				if (s_gr[g] == 0xFFFFFFFFu) s_gr[g] = nxr; else nxr = s_gr[g];
+			}
+			s_gcl[ng] = 0xFF; s_gi[ng] = s_ni; s_gr[ng] = s_nr;
+			s_ng = ng;
+		}
+		__syncthreads();
+		const uint32_t ng = s_ng, ni = s_ni, nr = s_nr;
+		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
+		const uint32_t* cpos = b.ch_pos + off;
+		const uint16_t* cev = b.ch_ev + off;
+		/* ---- 3. every group starts a run (sizes only) ... */
+		if (tid < ng)
+			s_run[tid] = batch_run<false>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, nullptr, nullptr, 0u);
+		__syncthreads();
+		/* ---- 4. ... the ones that count begin where the previous one ended */
+		if (tid == 0) {
+			uint32_t nh = 0, sp = 0, maxd = 0;
+			int32_t d = 0;
+			for (uint32_t g = 0; g < ng; g = s_run[g].last_group + 1u) {
+				s_hlist[nh] = g; s_hspan[nh] = sp;
+				sp += s_run[g].ns + (s_run[g].uncoupled ? 1u : 0u); /* + the new sentinel */
+				d += (int32_t)s_run[g].ns - (int32_t)(s_run[g].k_end - s_run[g].k_start);
+				s_hdelta[nh] = d;
+				const uint32_t adl = (uint32_t)(d < 0 ? -d : d);
+				maxd = adl > maxd ? adl : maxd;
+				my_cost += s_run[g].dcost;
+				nh++;
+			}
+			s_hspan[nh] = sp; s_nh = nh; s_maxd = maxd;
+			const uint32_t newlen = (uint32_t)((int32_t)len + d); /* (a run that ends at the sentinel un-coupled replaces everything up to it, and writes a new one) */
+			s_newlen = newlen;
+			uint32_t newoff = off, newcap = cap;
+			bool fail = maxd > 2047u;
+			if (!fail && newlen + 1u > cap) { /* the chain outgrew its slot: fresh space at the top of the pool */
+				newcap = (2u * (newlen + 1u) + 256u + 7u) & ~7u;
+				newoff = atomicAdd(b.pool_top, newcap);
+				if (newoff + newcap > b.pool_cap) fail = true;
+			}
+			s_newoff = newoff; s_newcap = newcap;
+			s_span_base = atomicAdd(&ab.hdr[6], sp);
+			if (s_span_base + sp > ab.span_cap) fail = true;
+			s_fail = fail ? 1u : 0u;
+		}
+		__syncthreads();
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		const uint32_t nh = s_nh, spb = s_span_base, noff = s_newoff, maxd = s_maxd;
+		const bool moved = noff != off;
+		/* ---- 5. the runs that count write their entries */
+		if (tid < nh) {
+			const uint32_t g = s_hlist[tid];
+			const RunOut r = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, spb + s_hspan[tid]);
+			if (r.uncoupled) { ab.span_pos[spb + s_hspan[tid] + r.ns] = MGL_POS_INF; ab.span_ev[spb + s_hspan[tid] + r.ns] = (uint16_t)r.end_p; }
+		}
+		/* ---- 6. the rewrite as copy jobs.  Pieces in chain order: [prefix] run 0, stretch 0, run 1, stretch 1, ... ; stretch h
+		 * = old entries [k_end(h), k_start(h + 1)) (the last one runs to the sentinel, included) and moves by the length change
+		 * accumulated up to run h.  In place: a stretch that does not move is left alone; one that moves goes in chunks that
+		 * are loaded whole, then stored (MGL_SPACE_SHIFT2), their first and last `maxd` entries -- all that the stores of
+		 * another piece can reach before the chunk is loaded -- coming from copies taken in pass B.  A chain that moves to a
+		 * new slot is simply copied piece by piece. */
+		__syncthreads();
+		/* count the jobs, reserve, then emit with the same loop (two sweeps over at most MGL_BATCH_MAX + 1 pieces per thread-0) */
+		if (tid == 0) {
+			uint32_t jb = 0, jc = 0, scr = 0;
+			if (moved) jb += (s_run[s_hlist[0]].k_start + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK; /* prefix to the new slot */
+			for (uint32_t h = 0; h < nh; h++) {
+				const RunOut& r = s_run[s_hlist[h]];
+				const uint32_t spn = r.ns + (r.uncoupled ? 1u : 0u);
+				jc += (spn + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK;
+				if (r.uncoupled) continue; /* nothing behind it */
+				const uint32_t s0 = r.k_end, s1 = h + 1u < nh ? s_run[s_hlist[h + 1u]].k_start : len + 1u;
+				const uint32_t cnt = s1 - s0;
+				if (cnt == 0 || (!moved && s_hdelta[h] == 0)) continue;
+				const uint32_t nchunks = (cnt + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK;
+				jc += nchunks;
+				if (!moved) { jb += 2u * nchunks; scr += 2u * maxd * nchunks; }
+			}
+			s_job_b = atomicAdd(&ab.hdr[4], jb);
+			s_job_c = atomicAdd(&ab.hdr[5], jc);
+			s_scr_base = atomicAdd(&ab.hdr[7], scr);
+			if (s_job_b + jb > ab.job_cap || s_job_c + jc > ab.job_cap || s_scr_base + scr > ab.scratch_cap) s_fail = 1;
+		}
+		__syncthreads();
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		if (tid == 0) {
+			uint32_t jb = s_job_b, jc = s_job_c, scr = s_scr_base;
+			if (moved) {
+				const uint32_t k0 = s_run[s_hlist[0]].k_start;
+				for (uint32_t at = 0; at < k0; at += MGL_JOB_CHUNK)
+					ab.jobs_b[jb++] = make_uint4(off + at, noff + at, (k0 - at) < MGL_JOB_CHUNK ? (k0 - at) : MGL_JOB_CHUNK, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8));
+			}
+			for (uint32_t h = 0; h < nh; h++) {
+				const RunOut& r = s_run[s_hlist[h]];
+				const int32_t dprev = h ? s_hdelta[h - 1u] : 0;
+				const uint32_t spn = r.ns + (r.uncoupled ? 1u : 0u);
+				const uint32_t dst0 = (uint32_t)((int32_t)r.k_start + dprev);
+				for (uint32_t at = 0; at < spn; at += MGL_JOB_CHUNK)
+					ab.jobs_c[jc++] = make_uint4(spb + s_hspan[h] + at, noff + dst0 + at, (spn - at) < MGL_JOB_CHUNK ? (spn - at) : MGL_JOB_CHUNK, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8));
+				if (r.uncoupled) continue;
+				const uint32_t s0 = r.k_end, s1 = h + 1u < nh ? s_run[s_hlist[h + 1u]].k_start : len + 1u;
+				const uint32_t cnt = s1 - s0;
+				const int32_t d = s_hdelta[h];
+				if (cnt == 0 || (!moved && d == 0)) continue;
+				for (uint32_t at = 0; at < cnt; at += MGL_JOB_CHUNK) {
+					const uint32_t n1 = (cnt - at) < MGL_JOB_CHUNK ? (cnt - at) : MGL_JOB_CHUNK;
+					if (moved) { ab.jobs_c[jc++] = make_uint4(off + s0 + at, (uint32_t)((int32_t)(noff + s0 + at) + d), n1, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8)); continue; }
+					const uint32_t sl = maxd < n1 ? maxd : n1; /* a chunk shorter than maxd is saved whole (both slivers overlap) */
+					ab.jobs_b[jb++] = make_uint4(off + s0 + at, scr, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
+					ab.jobs_b[jb++] = make_uint4(off + s0 + at + n1 - sl, scr + maxd, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
+					const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+					ab.jobs_c[jc++] = make_uint4(off + s0 + at, scr, n1, MGL_SPACE_SHIFT2 | (ad << 8) | (d < 0 ? 1u << 20 : 0u) | (maxd << 21));
+					scr += 2u * maxd;
+				}
+			}
+			b.ch_len[cx] = s_newlen;
+			if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
+		}
+		/* ---- 7. dense checkpoints: this context's value wherever its trajectory changed */
+		for (uint32_t h = 0; h < nh; h++) {
+			const RunOut& r = s_run[s_hlist[h]];
+			const uint32_t lo = r.lo, hi = r.hi;
+			const uint32_t first = spb + s_hspan[h], last = first + r.ns;
+			const uint32_t ck_lo = (lo > MGL_MAX_MATCH ? lo - MGL_MAX_MATCH : 0u) >> MGL_CK2_SHIFT;
+			const uint32_t ck_hi = hi == MGL_POS_INF ? b.nck : ((hi >> MGL_CK2_SHIFT) + 1u < b.nck ? (hi >> MGL_CK2_SHIFT) + 1u : b.nck);
+			__syncthreads(); /* the run's entries are in the span area (step 5, another thread's stores) */
+			for (uint32_t ck = ck_lo + tid; ck < ck_hi; ck += blockDim.x) {
+				const uint32_t P = ckpt_boundary(b, ck); /* on the NEW walk (the bitmaps are committed); MGL_POS_INF: the final model */
+				if (P <= lo || P > hi) continue;
+				uint32_t a = first, z = last;
+				while (a < z) { const uint32_t mid = (a + z) >> 1; if (ab.span_pos[mid] < P) a = mid + 1; else z = mid; }
+				const uint16_t v = a < last ? (uint16_t)(ab.span_ev[a] & 0x7FFu) : (uint16_t)r.end_p;
+				b.ck_probs[(size_t)ck * b.ck_elems + cx] = v;
+			}
+		}
+	}
+	if (tid == 0 && my_cost) atomicAdd((unsigned long long*)&bt.acc[0], (unsigned long long)my_cost);
+}
+
+/* totals of a batch accept into Control: the new base's exact cost, its packet count */
+__global__ void k_batch_end(Control* ctl, BatchBuf bt)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	if (bt.hdr[0] != 1u || ctl->apply_failed) return;
+	const uint64_t base_cost = ctl->cur_cost ? ctl->cur_cost : ctl->rebuild_cost;
+	ctl->rebuild_cost = (uint64_t)((long long)base_cost + bt.acc[0] + bt.acc[1]);
+	ctl->packets = (uint64_t)((long long)ctl->packets + bt.acc[2]);
+	bt.hdr[0] = 3u; /* done */
+}

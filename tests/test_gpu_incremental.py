@@ -1,6 +1,8 @@
 """The incremental engine's base structures (bitmaps, special-state records, dense
 checkpoints, per-context event chains) against the CPU oracle's event trace, and the two
 device engines against each other.  `-m gpu`."""
+import lzma
+
 import numpy as np
 import pytest
 
@@ -183,6 +185,41 @@ def test_incremental_accept_equals_rebuild(name, K, steps, golden, golden_input)
     assert accepted >= 5
     inc.close()
     ref.close()
+
+
+@pytest.mark.parametrize("name,K,steps", [("lorem4k", 96, 80), ("enwik3k", 128, 80), ("reps", 64, 80), ("zeros600", 32, 40)])
+def test_batch_accept_equals_rebuild(name, K, steps, golden, golden_input, monkeypatch):
+    """Bulk steps that take at most MGL_BATCH_MAX moves patch the base for all of them at once (mgl_kernels5.hip) instead of
+    re-deriving it: after every such step bitmaps, special-state records, chains and dense checkpoints are identical to a
+    rebuild from the slab, the cost is the oracle's walk of the slab, and a chain with the batch path switched off
+    (MGL_NO_BATCH: every bulk step a rebuild) walks the same trajectory."""
+    data = golden_input(name)
+    inc = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=5, iters_per_epoch=10**7)
+    monkeypatch.setenv("MGL_NO_BATCH", "1")
+    full = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=5, iters_per_epoch=10**7)
+    monkeypatch.delenv("MGL_NO_BATCH")
+    ref = binding.SA(data, accept="single", neighbours_per_step=8, seed=5)
+    o = Oracle(data, dict_limit=0x400000)
+    moves = multi = 0
+    for s in range(steps):
+        st, sf = inc.run(1), full.run(1)
+        assert st["current_cost"] == sf["current_cost"] and st["accepted"] == sf["accepted"] and st["best_cost"] == sf["best_cost"], (name, s)
+        assert st["bulk_rollbacks"] == 0 and st["full_rebuilds"] == 0
+        moves += st["accepted"]
+        multi += st["accepted"] > 1
+        if st["accepted"] and (s < 25 or s % 5 == 0):
+            cur, cost = inc.current()
+            assert (cur == full.current()[0]).all()
+            assert cost == o.cost_slab(cur.astype(literal_slab(1).dtype))["total"], s
+            ref.set_slab(cur)
+            assert_same_base(canonical_base(inc, cur), canonical_base(ref, cur), (name, s))
+    assert moves >= 10 and (multi >= 3 or name == "zeros600")   # (600 zeros: one window covers the file, one move per step)
+    ia, ib = inc.batch_counters()
+    assert ia >= 3                      # the batch path really ran
+    assert full.batch_counters() == (0, 0)
+    bst, _ = inc.best()
+    assert lzma.decompress(binding.emit_stream(data, bst), format=lzma.FORMAT_ALONE) == data
+    inc.close(); full.close(); ref.close()
 
 
 @pytest.mark.parametrize("name,K", [("lorem4k", 64), ("enwik3k", 96)])

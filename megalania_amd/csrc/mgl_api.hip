@@ -140,6 +140,7 @@ struct mgl_sa {
 	BulkBuf bulk;
 	BatchBuf batch;               /* a bulk step that took few moves patches the base instead of rebuilding it (mgl_kernels5.hip) */
 	bool batch_ok = false;
+	bool select_small = false;    /* the previous bulk step had few acceptable neighbours: this one's selection runs as one launch */
 	uint64_t batch_accepts = 0, batch_fallbacks = 0; /* bulk steps whose moves were patched in / that went to the rebuild although a batch accept began */
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
 	uint32_t force_rollbacks = 0;  /* diagnostic: treat the next so many bulk steps that took moves as failed validations */
@@ -608,7 +609,9 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	{
 		BatchBuf& bt = sa->batch;
 		dfree(bt.hdr); dfree(bt.cl); dfree(bt.jpos); dfree(bt.jnew); dfree(bt.jold); dfree(bt.st_ikey); dfree(bt.st_rkey); dfree(bt.st_ipos);
-		dfree(bt.st_rpos); dfree(bt.ops); dfree(bt.ins_cl); dfree(bt.rem_cl); dfree(bt.ctxbits); dfree(bt.acc);
+		dfree(bt.st_rpos); dfree(bt.ops); dfree(bt.ins_cl); dfree(bt.rem_cl); dfree(bt.acc); dfree(bt.runs);
+		dfree(bt.cnt_i); dfree(bt.cnt_r); dfree(bt.off_i); dfree(bt.off_r); dfree(bt.cur_i); dfree(bt.cur_r);
+		dfree(bt.bk_ipos); dfree(bt.bk_rpos); dfree(bt.bk_ibit); dfree(bt.bk_icl); dfree(bt.bk_rcl);
 	}
 	for (hipEvent_t e : sa->ev_sim_pool) if (e) (void)hipEventDestroy(e);
 	dfree(sa->d_todo2); dfree(sa->d_todo3); dfree(sa->d_counts); dfree(sa->big.sim_hdr2); dfree(sa->big.sim_slot2); dfree(sa->d_pickrec); dfree(sa->d_pickstate);
@@ -911,7 +914,18 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&bt.ops, sizeof(uint4) * 2 * (size_t)MGL_BATCH_MAX * MGL_BATCH_OPCAP));
 			HIPCHK(hipMalloc(&bt.ins_cl, MGL_BATCH_ALLOC));
 			HIPCHK(hipMalloc(&bt.rem_cl, MGL_BATCH_ALLOC));
-			HIPCHK(hipMalloc(&bt.ctxbits, sizeof(uint32_t) * 512));
+			bt.nctx = L.total;
+			bt.runs_cap = 1u << 17;
+			HIPCHK(hipMalloc(&bt.runs, sizeof(uint4) * 2 * (size_t)bt.runs_cap));
+			for (uint32_t** p : { &bt.cnt_i, &bt.cnt_r, &bt.off_i, &bt.off_r, &bt.cur_i, &bt.cur_r }) {
+				HIPCHK(hipMalloc(p, sizeof(uint32_t) * (bt.nctx + 64u)));
+				HIPCHK(hipMemset(*p, 0, sizeof(uint32_t) * (bt.nctx + 64u)));
+			}
+			HIPCHK(hipMalloc(&bt.bk_ipos, sizeof(uint32_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.bk_rpos, sizeof(uint32_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.bk_ibit, sizeof(uint16_t) * MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.bk_icl, MGL_BATCH_ALLOC));
+			HIPCHK(hipMalloc(&bt.bk_rcl, MGL_BATCH_ALLOC));
 			HIPCHK(hipMalloc(&bt.acc, sizeof(long long) * 4));
 			HIPCHK(hipMemset(bt.acc, 0, sizeof(long long) * 4));
 			sa->batch_ok = sa->incremental_apply && getenv("MGL_NO_BATCH") == nullptr;
@@ -1060,7 +1074,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 
 	sa->sqrt_thresh = ceil_sqrt_u64(sa->cfg.iters_per_epoch);
 	/* a bulk step costs a parallel rebuild (about 3 single steps at 100 KB, 6 at 10 MB, 20 at 100 MB) */
-	sa->bulk_threshold = getenv("MGL_BULK_THRESHOLD") ? (uint32_t)atoi(getenv("MGL_BULK_THRESHOLD")) : (n <= (1u << 20) ? 16u : n <= (1u << 24) ? 32u : 128u);
+	/* ... unless the step takes few moves: those are patched in at once (mgl_kernels5.hip) for about half a single step's time, so a bulk
+	 * step pays as soon as it can be expected to take two moves */
+	sa->bulk_threshold = getenv("MGL_BULK_THRESHOLD") ? (uint32_t)atoi(getenv("MGL_BULK_THRESHOLD"))
+	                     : sa->batch_ok ? 2u : (n <= (1u << 20) ? 16u : n <= (1u << 24) ? 32u : 128u);
 	if (sa->bulk_threshold == 0) sa->bulk_threshold = 1;
 
 	/* packet_slab_new: all-literal current and best slabs */
@@ -1147,7 +1164,7 @@ extern "C" int mgl_sa_begin_epoch(mgl_sa* sa, unsigned phase, int from_best)
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
 	/* MGL_ACCEPT_AUTO starts every epoch the same way, whatever the previous one left behind: a fresh block, bulk steps
 	 * first from the all-literal slab (thousands of improving neighbours), single steps first from the best slab */
-	sa->bulk_now = !from_best; sa->bulk_hold = 0; sa->blk_done = 0;
+	sa->bulk_now = !from_best; sa->bulk_hold = 0; sa->blk_done = 0; sa->select_small = false;
 	if (from_best && base_is_best) return MGL_OK; /* main.c:73-76 would copy packets_best over itself */
 	if (snaps) {
 		SnapMeta meta[2];
@@ -1193,7 +1210,7 @@ extern "C" int mgl_sa_set_slab(mgl_sa* sa, const mgl_packet* packets)
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
 	if ((rc = keep_best_before_overwrite(sa, c))) return rc;
-	sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; /* MGL_ACCEPT_AUTO starts over on a new slab */
+	sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; sa->select_small = false; /* MGL_ACCEPT_AUTO starts over on a new slab */
 	if ((rc = import_slab(sa, packets, sa->base.v.slab))) return rc;
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
 	if ((rc = write_ctl(sa, sa->base, &c))) return rc;
@@ -1221,7 +1238,7 @@ extern "C" int mgl_sa_seed_greedy(mgl_sa* sa, uint32_t candidates)
 	int rc = read_ctl(sa, sa->base, &c);
 	if (rc) return rc;
 	if ((rc = keep_best_before_overwrite(sa, c))) return rc;
-	sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; /* MGL_ACCEPT_AUTO starts over on a new slab */
+	sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; sa->select_small = false; /* MGL_ACCEPT_AUTO starts over on a new slab */
 	hipLaunchKernelGGL(k_greedy_seed, dim3((sa->ctx.n + 255u) / 256u), dim3(256), 0, sa->stream, sa->ctx, sa->base.v.slab, candidates);
 	HIPCHK(hipGetLastError());
 	c.cur_cost = 0; c.accepted_flag = 0; c.copy_best_flag = 0; c.error_flags = 0;
@@ -1243,7 +1260,7 @@ static hipEvent_t pool_event(mgl_sa* sa, size_t i)
 }
 
 /* MGL_ACCEPT_AUTO starts over: a fresh block, bulk steps first (a new slab says nothing about the old one's windows) */
-static void auto_reset(mgl_sa* sa) { sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; }
+static void auto_reset(mgl_sa* sa) { sa->bulk_now = true; sa->bulk_hold = 0; sa->blk_done = 0; sa->select_small = false; }
 extern "C" int mgl_sa_set_accept_mode(mgl_sa* sa, int mode, uint32_t bulk_threshold)
 {
 	if (!sa) return fail(MGL_EINVAL, "null handle");
@@ -1270,7 +1287,9 @@ static void auto_decide(mgl_sa* sa, bool was_bulk, uint64_t block, uint64_t impr
 {
 	const bool many = improving >= (uint64_t)sa->bulk_threshold * block;
 	if (was_bulk) {
-		if (taken < 4u * block) { sa->bulk_now = false; sa->bulk_hold = 48; }
+		/* (a bulk step that takes one move is a single step at a higher price: from the all-literal slab, where no window
+		 * closes, or once improving neighbours have become rare) */
+		if (sa->batch_ok ? 2u * taken < 3u * block : taken < 4u * block) { sa->bulk_now = false; sa->bulk_hold = 48; }
 		else sa->bulk_now = many;
 		return;
 	}
@@ -1292,7 +1311,9 @@ static int launch_bulk_tail(mgl_sa* sa)
 	const DecideArgs a = decide_args(sa);
 	const uint32_t blocks = (K + 255u) / 256u;
 	hipLaunchKernelGGL(k_bulk_prep, dim3(blocks), dim3(256), 0, sa->stream, sa->ctx, sa->base.ctl, sa->nbr, a, sa->bulk);
-	for (uint32_t r = 0; r < MGL_BULK_ROUNDS; r++) {
+	if (sa->select_small) {
+		hipLaunchKernelGGL(k_bulk_select_small, dim3(1), dim3(1024), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, K);
+	} else for (uint32_t r = 0; r < MGL_BULK_ROUNDS; r++) {
 		hipLaunchKernelGGL(k_bulk_pairs, dim3(blocks, blocks), dim3(256), 0, sa->stream, sa->bulk, K, r);
 		hipLaunchKernelGGL(k_bulk_round, dim3(blocks), dim3(256), 0, sa->stream, sa->base.ctl, sa->nbr, sa->bulk, sa->base.v.slab, K, r);
 	}
@@ -1304,13 +1325,15 @@ static int launch_bulk_tail(mgl_sa* sa)
 	uint32_t bstat[8] = { 2u, 0, 0, 0, 0, 0, 0, 0 }; /* without the batch path: everything is the rebuild's */
 	if (sa->batch_ok) {
 		Base2& b = sa->b2;
-		hipLaunchKernelGGL(k_batch_clusters, dim3(1), dim3(256), 0, sa->stream, sa->ctx, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->batch);
+		hipLaunchKernelGGL(k_batch_clusters, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->batch);
 		hipLaunchKernelGGL(k_batch_walk, dim3(MGL_BATCH_MAX), dim3(64), 0, sa->stream, sa->ctx, b, sa->batch);
 		hipLaunchKernelGGL(k_batch_commit, dim3(MGL_BATCH_MAX), dim3(256), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
 		hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, sa->stream, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
 		hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, sa->stream, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
-		hipLaunchKernelGGL(k_batch_ctxlist, dim3(1), dim3(64), 0, sa->stream, sa->batch, sa->ab);
-		hipLaunchKernelGGL(k_batch_chains, dim3(sa->apply_blocks), dim3(MGL_BATCH_THREADS), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_batch_scan, dim3(1), dim3(1024), 0, sa->stream, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_batch_fill, dim3(256), dim3(256), 0, sa->stream, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_batch_chains, dim3(sa->batch.nctx), dim3(MGL_BATCH_THREADS), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_batch_ckpt, dim3(1024, 8), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->batch, sa->ab);
 		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 0, (const uint32_t*)sa->batch.hdr);
 		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 1, (const uint32_t*)sa->batch.hdr);
 		hipLaunchKernelGGL(k_batch_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->batch);
@@ -1318,6 +1341,7 @@ static int launch_bulk_tail(mgl_sa* sa)
 		HIPCHK(hipMemcpyAsync(bstat, sa->batch.hdr, sizeof bstat, hipMemcpyDeviceToHost, sa->stream));
 		HIPCHK(hipStreamSynchronize(sa->stream));
 	}
+	if (sa->batch_ok) sa->select_small = bstat[7] <= 512u; /* this step's acceptable neighbours size the next step's selection */
 	if (bstat[0] == 3u) sa->batch_accepts++; /* the moves are in: structures patched, exact cost in Control::rebuild_cost, every rep packet of the new walk checked */
 	else if (bstat[0] != 0u) {
 		/* the rebuild's: the journals into the slab (unless the batch accept got as far as writing them: status 1 = it gave

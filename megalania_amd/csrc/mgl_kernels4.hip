@@ -272,6 +272,56 @@ __global__ void __launch_bounds__(256) k_bulk_write(Control* ctl, NbrOut out, Bu
 	}
 }
 
+/* The same selection -- the same MGL_BULK_ROUNDS synchronous rounds, the same verdicts -- by one workgroup in one launch, for
+ * steps with few acceptable neighbours (the sixteen launches of the tiled form cost 75 us whatever they find to do; the host
+ * picks this form when the previous step had at most 512 candidates).  Any number of candidates is handled (in tiles of
+ * 1024 through LDS), only slowly beyond a few thousand. */
+__global__ void __launch_bounds__(1024) k_bulk_select_small(Control* ctl, NbrOut out, BulkBuf bb, uint32_t K)
+{
+	__shared__ uint64_t s_key[1024];
+	__shared__ uint4 s_win[1024];
+	__shared__ uint8_t s_st[1024];
+	const uint32_t n = (uint32_t)bb.hdr[0];
+	const uint32_t tid = threadIdx.x;
+	(void)ctl; (void)out;
+	/* states live in cstate[0 .. K) (previous round) and cstate[K .. 2K) (next round), as in the tiled form */
+	for (uint32_t a = tid; a < n; a += blockDim.x) bb.cstate[a] = 0;
+	__syncthreads();
+	for (uint32_t round = 0; round < MGL_BULK_ROUNDS; round++) {
+		const uint8_t* st_in = bb.cstate + (size_t)(round & 1u) * K;
+		uint8_t* st_out = bb.cstate + (size_t)((round + 1u) & 1u) * K;
+		for (uint32_t a0 = 0; a0 < n; a0 += blockDim.x) {
+			const uint32_t a = a0 + tid;
+			const bool mine = a < n;
+			const uint8_t my = mine ? st_in[a] : (uint8_t)2;
+			uint64_t key = 0; uint4 w = make_uint4(0, 0, 0, 0);
+			if (mine) { key = bb.ckey[a]; w = bb.cwin[a]; }
+			uint32_t f = 0;
+			for (uint32_t t0 = 0; t0 < n; t0 += 1024u) {
+				__syncthreads();
+				if (t0 + tid < n) { s_key[tid] = bb.ckey[t0 + tid]; s_win[tid] = bb.cwin[t0 + tid]; s_st[tid] = st_in[t0 + tid]; }
+				__syncthreads();
+				if (mine && my == 0) {
+					const uint32_t cnt = (n - t0) < 1024u ? (n - t0) : 1024u;
+					for (uint32_t i = 0; i < cnt; i++)
+						if (s_st[i] != 2 && s_key[i] < key && windows_conflict(s_win[i], w)) f |= s_st[i] == 1 ? 1u : 2u;
+				}
+			}
+			if (mine) {
+				const uint8_t now = my ? my : ((f & 1u) ? (uint8_t)2 : ((f & 2u) ? (uint8_t)0 : (uint8_t)1));
+				st_out[a] = now;
+				if (my == 0 && now == 1) {
+					const unsigned long long at = atomicAdd(&bb.hdr[1], 1ull);
+					bb.taken[at] = (uint32_t)(key & 0xFFFFFu);
+					atomicMin(&bb.hdr[6], (unsigned long long)key);
+				}
+			}
+		}
+		__syncthreads();
+		__threadfence_block();
+	}
+}
+
 /* bookkeeping between the selection and the rebuild */
 __global__ void k_bulk_end(Control* ctl, BulkBuf bb, DecideArgs a)
 {

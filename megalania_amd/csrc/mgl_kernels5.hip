@@ -41,6 +41,7 @@
 #define MGL_BATCH_EVCAP 4096u  /* inserted / removed events staged per cluster */
 #define MGL_BATCH_OPCAP 2048u  /* bitmap / state-record ops per cluster */
 #define MGL_BATCH_SUB 1024u    /* events of one kind per context */
+#define MGL_BATCH_GAP 32u      /* events of a context further apart than this start a group of their own */
 #define MGL_BATCH_ALLOC (MGL_BATCH_MAX * MGL_BATCH_EVCAP) /* entries of the combined event lists (ApplyBuf lists are allocated this long) */
 
 struct BatchBuf {
@@ -53,7 +54,17 @@ struct BatchBuf {
 	uint16_t* st_ikey; uint32_t* st_ipos; uint16_t* st_rkey; uint32_t* st_rpos; /* per cluster MGL_BATCH_EVCAP */
 	uint4* ops;         /* per cluster MGL_BATCH_OPCAP x 2: {pos, flags | count << 8, ctx_state, d0} {d1, d2, d3, 0} */
 	uint8_t* ins_cl; uint8_t* rem_cl; /* cluster of every event of the combined lists */
-	uint32_t* ctxbits;  /* 512 words: touched contexts */
+	/* the combined lists again, bucketed by context (k_batch_scan / k_batch_fill): per context its inserted and removed events,
+	 * in any order (k_batch_chains sorts its own few by position) */
+	uint32_t* cnt_i; uint32_t* cnt_r;   /* per context: events (counted by k_batch_commit) */
+	uint32_t* off_i; uint32_t* off_r;   /* exclusive scans */
+	uint32_t* cur_i; uint32_t* cur_r;   /* fill cursors */
+	uint32_t* bk_ipos; uint16_t* bk_ibit; uint8_t* bk_icl; /* MGL_BATCH_ALLOC each */
+	uint32_t* bk_rpos; uint8_t* bk_rcl;
+	uint32_t nctx;      /* contexts (DevCtx::L.total) */
+	uint4* runs;        /* the runs that count, two words of four each: {context, lo, hi, first span entry} {entries, end probability, -, -}:
+	                     * k_batch_ckpt patches the dense checkpoints along them (hdr[8] = how many) */
+	uint32_t runs_cap;
 	long long* acc;     /* [0] cost change summed by k_batch_chains [1] direct-bit cost change [2] packets on the walk, change */
 };
 #define MGL_OP_ON 1u     /* position joins the walk */
@@ -62,10 +73,10 @@ struct BatchBuf {
 #define MGL_OP_PLAIN 8u  /* position is a literal of the new walk: special bit off */
 
 /* ------------------------------------------------------------------ clusters */
-__global__ void __launch_bounds__(256) k_batch_clusters(DevCtx c, const Control* ctl, NbrOut out, BulkBuf bb, BatchBuf bt)
+__global__ void __launch_bounds__(1024) k_batch_clusters(DevCtx c, const Control* ctl, NbrOut out, BulkBuf bb, BatchBuf bt)
 {
 	__shared__ uint32_t s_j[MGL_BATCH_MAX], s_t[MGL_BATCH_MAX], s_e[MGL_BATCH_MAX], s_nd[MGL_BATCH_MAX], s_ord[MGL_BATCH_MAX];
-	__shared__ uint32_t s_joff[MGL_BATCH_MAX + 1];
+	__shared__ uint32_t s_joff[MGL_BATCH_MAX + 1], s_cl[MGL_BATCH_MAX * 2];
 	__shared__ uint32_t s_ncl, s_bad;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t m = (uint32_t)bb.hdr[1];
@@ -73,11 +84,13 @@ __global__ void __launch_bounds__(256) k_batch_clusters(DevCtx c, const Control*
 		s_bad = 0; s_ncl = 0;
 		bt.hdr[0] = m == 0 ? 0u : (m > MGL_BATCH_MAX ? 2u : 1u);
 		bt.hdr[1] = 0; bt.hdr[2] = 0; bt.hdr[3] = 0; bt.hdr[4] = 0; bt.hdr[5] = 0; bt.hdr[6] = 0;
+		bt.hdr[8] = 0;
+		bt.hdr[7] = (uint32_t)bb.hdr[0]; /* acceptable neighbours of this step: the host sizes the next step's selection by it */
 		bt.acc[0] = 0; bt.acc[1] = 0; bt.acc[2] = 0;
 	}
-	for (uint32_t i = tid; i < 512; i += blockDim.x) bt.ctxbits[i] = 0;
 	if (m == 0 || m > MGL_BATCH_MAX) return;
-	(void)ctl;
+	for (uint32_t i = tid; i < bt.nctx; i += blockDim.x) { bt.cnt_i[i] = 0; bt.cnt_r[i] = 0; bt.cur_i[i] = 0; bt.cur_r[i] = 0; }
+	(void)ctl; (void)c;
 	if (tid < m) {
 		const uint32_t j = bb.taken[tid];
 		s_j[tid] = j; s_t[tid] = out.win[2u * j]; s_e[tid] = out.win[2u * j + 1u]; s_nd[tid] = out.ndiffs[j];
@@ -97,31 +110,50 @@ __global__ void __launch_bounds__(256) k_batch_clusters(DevCtx c, const Control*
 			s_joff[r] = joff;
 			if (s_nd[i] == 0) continue; /* a taken neighbour that changes nothing (its mutation re-made the packet that was there) */
 			if (ncl == 0 || s_t[i] >= reach) { /* walk and base agree entirely from `reach` on: a new cluster */
-				if (ncl) bt.cl[(ncl - 1u) * 8u + 1u] = joff - bt.cl[(ncl - 1u) * 8u];
-				bt.cl[ncl * 8u] = joff; bt.cl[ncl * 8u + 5u] = s_t[i];
+				if (ncl) s_cl[(ncl - 1u) * 2u + 1u] = joff - s_cl[(ncl - 1u) * 2u];
+				s_cl[ncl * 2u] = joff;
 				ncl++;
 			}
 			joff += s_nd[i];
 			reach = s_e[i] > reach ? s_e[i] : reach;
 		}
 		s_joff[m] = joff;
-		if (ncl) bt.cl[(ncl - 1u) * 8u + 1u] = joff - bt.cl[(ncl - 1u) * 8u];
+		if (ncl) s_cl[(ncl - 1u) * 2u + 1u] = joff - s_cl[(ncl - 1u) * 2u];
 		s_ncl = ncl;
-		for (uint32_t q = 0; q < ncl; q++) if (bt.cl[q * 8u + 1u] > MGL_BATCH_JCAP) s_bad = 1;
+		for (uint32_t q = 0; q < ncl; q++) if (s_cl[q * 2u + 1u] > MGL_BATCH_JCAP) s_bad = 1;
 	}
 	__syncthreads();
-	/* the merged journals: member after member (a member's entries all lie before the next member's target) */
-	for (uint32_t r = 0; r < m; r++) {
-		const uint32_t i = s_ord[r], j = s_j[i], nd = s_nd[i], at = s_joff[r];
-		for (uint32_t e = tid; e < nd; e += blockDim.x) {
-			const size_t k = (size_t)j * MGL_MAX_DIFFS + e;
-			bt.jpos[at + e] = out.dpos[k]; bt.jnew[at + e] = out.dnew[k]; bt.jold[at + e] = out.dold[k];
-		}
+	if (tid < s_ncl) { bt.cl[tid * 8u] = s_cl[tid * 2u]; bt.cl[tid * 8u + 1u] = s_cl[tid * 2u + 1u]; }
+	/* the merged journals: member after member (a member's entries all lie before the next member's target); one thread per
+	 * (member, entry) */
+	for (uint32_t x = tid; x < m * MGL_MAX_DIFFS; x += blockDim.x) {
+		const uint32_t r = x / MGL_MAX_DIFFS, e = x - r * MGL_MAX_DIFFS;
+		const uint32_t i = s_ord[r];
+		if (e >= s_nd[i]) continue;
+		const size_t k = (size_t)s_j[i] * MGL_MAX_DIFFS + e;
+		const uint32_t at = s_joff[r] + e;
+		bt.jpos[at] = out.dpos[k]; bt.jnew[at] = out.dnew[k]; bt.jold[at] = out.dold[k];
 	}
 	__syncthreads();
 	/* ... which must come out strictly ascending: two taken journals on one entry (or out of order) are the rebuild's business */
 	const uint32_t tot = s_joff[m];
-	for (uint32_t e = tid; e + 1u < tot; e += blockDim.x) if (bt.jpos[e] >= bt.jpos[e + 1u]) s_bad = 1;
+	for (uint32_t x = tid; x < m * MGL_MAX_DIFFS; x += blockDim.x) {
+		const uint32_t r = x / MGL_MAX_DIFFS, e = x - r * MGL_MAX_DIFFS;
+		const uint32_t i = s_ord[r];
+		if (e >= s_nd[i]) continue;
+		const uint32_t at = s_joff[r] + e;
+		if (at + 1u >= tot) continue;
+		/* the next entry of the merged journal: this member's next one, or the first one of the next member that has any */
+		const size_t k = (size_t)s_j[i] * MGL_MAX_DIFFS + e;
+		uint32_t nxt;
+		if (e + 1u < s_nd[i]) nxt = out.dpos[k + 1];
+		else {
+			uint32_t r2 = r + 1u;
+			while (r2 < m && s_nd[s_ord[r2]] == 0) r2++;
+			nxt = r2 < m ? out.dpos[(size_t)s_j[s_ord[r2]] * MGL_MAX_DIFFS] : 0xFFFFFFFFu;
+		}
+		if (out.dpos[k] >= nxt) s_bad = 1;
+	}
 	__syncthreads();
 	if (tid == 0) {
 		bt.hdr[1] = s_ncl; bt.hdr[5] = tot;
@@ -155,13 +187,11 @@ __global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf b
 {
 	__shared__ uint32_t s_jpos[MGL_BATCH_JCAP];
 	__shared__ mgl_pk s_jnew[MGL_BATCH_JCAP];
-	__shared__ uint32_t s_ctxbits[512];
 	if (bt.hdr[0] != 1u) return;
 	const uint32_t cl = blockIdx.x, lane = threadIdx.x;
 	if (cl >= bt.hdr[1]) return;
 	const uint32_t j0 = bt.cl[cl * 8u], nd = bt.cl[cl * 8u + 1u];
 	for (uint32_t i = lane; i < nd; i += 64) { s_jpos[i] = bt.jpos[j0 + i]; s_jnew[i] = bt.jnew[j0 + i]; }
-	for (uint32_t i = lane; i < 512; i += 64) s_ctxbits[i] = 0;
 	wave_sync();
 	const uint32_t t = s_jpos[0], last_j = s_jpos[nd - 1];
 	uint16_t* ikey = bt.st_ikey + (size_t)cl * MGL_BATCH_EVCAP; uint32_t* ipos = bt.st_ipos + (size_t)cl * MGL_BATCH_EVCAP;
@@ -231,7 +261,6 @@ __global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf b
 					mgl_plan_event(&npl, lane, &ctx, &bit);
 					ikey[n_ins + lane] = (uint16_t)(ctx | (bit << 15));
 					ipos[n_ins + lane] = p;
-					atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
 				}
 				n_ins += npl.nev;
 				ddirect += (long long)((uint64_t)npl.ndirect << 11);
@@ -241,8 +270,7 @@ __global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf b
 						mgl_plan_event(&bpl, lane, &ctx, &bit);
 						rkey[n_rem + lane] = (uint16_t)ctx;
 						rpos[n_rem + lane] = p;
-						atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
-					}
+						}
 					n_rem += bpl.nev;
 					ddirect -= (long long)((uint64_t)bpl.ndirect << 11);
 				}
@@ -282,8 +310,7 @@ __global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf b
 							mgl_plan_event(&pl, slot, &ctx, &bit);
 							rkey[n_rem + i * 9u + slot] = (uint16_t)ctx;
 							rpos[n_rem + i * 9u + slot] = p;
-							atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
-						}
+								}
 						n_rem += 9u * take;
 						batch_op(bt, cl, nops, failed, q, MGL_OP_OFF, take, bs, lane);
 						dpackets -= (int32_t)take;
@@ -302,7 +329,6 @@ __global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf b
 				mgl_plan_event(&bpl, lane, &ctx, &bit);
 				rkey[n_rem + lane] = (uint16_t)ctx;
 				rpos[n_rem + lane] = q;
-				atomicOr(&s_ctxbits[ctx >> 5], 1u << (ctx & 31u));
 			}
 			n_rem += bpl.nev;
 			ddirect -= (long long)((uint64_t)bpl.ndirect << 11);
@@ -312,7 +338,6 @@ __global__ void __launch_bounds__(64) k_batch_walk(DevCtx c, Base2 b, BatchBuf b
 		}
 	}
 	wave_sync();
-	for (uint32_t i = lane; i < 512; i += 64) if (s_ctxbits[i]) atomicOr(&bt.ctxbits[i], s_ctxbits[i]);
 	if (lane == 0) {
 		bt.cl[cl * 8u + 2u] = n_ins; bt.cl[cl * 8u + 3u] = n_rem; bt.cl[cl * 8u + 4u] = nops;
 		if (failed || invalid) atomicOr(&bt.hdr[4], invalid ? 2u : 1u);
@@ -335,8 +360,16 @@ __global__ void __launch_bounds__(256) k_batch_commit(DevCtx c, Base2 b, Control
 	const uint32_t n_ins = bt.cl[cl * 8u + 2u], n_rem = bt.cl[cl * 8u + 3u], nops = bt.cl[cl * 8u + 4u];
 	if (cl == ncl - 1u && tid == 0) { bt.hdr[2] = ioff + n_ins; bt.hdr[3] = roff + n_rem; }
 	const size_t sb = (size_t)cl * MGL_BATCH_EVCAP;
-	for (uint32_t e = tid; e < n_ins; e += blockDim.x) { ab.ins_key[ioff + e] = bt.st_ikey[sb + e]; ab.ins_pos[ioff + e] = bt.st_ipos[sb + e]; bt.ins_cl[ioff + e] = (uint8_t)cl; }
-	for (uint32_t e = tid; e < n_rem; e += blockDim.x) { ab.rem_key[roff + e] = bt.st_rkey[sb + e]; ab.rem_pos[roff + e] = bt.st_rpos[sb + e]; bt.rem_cl[roff + e] = (uint8_t)cl; }
+	for (uint32_t e = tid; e < n_ins; e += blockDim.x) {
+		const uint16_t key = bt.st_ikey[sb + e];
+		ab.ins_key[ioff + e] = key; ab.ins_pos[ioff + e] = bt.st_ipos[sb + e]; bt.ins_cl[ioff + e] = (uint8_t)cl;
+		atomicAdd(&bt.cnt_i[key & 0x7FFFu], 1u);
+	}
+	for (uint32_t e = tid; e < n_rem; e += blockDim.x) {
+		const uint16_t key = bt.st_rkey[sb + e];
+		ab.rem_key[roff + e] = key; ab.rem_pos[roff + e] = bt.st_rpos[sb + e]; bt.rem_cl[roff + e] = (uint8_t)cl;
+		atomicAdd(&bt.cnt_r[key], 1u);
+	}
 	/* bitmaps and state records */
 	for (uint32_t o = tid; o < nops; o += blockDim.x) {
 		const uint4 a = bt.ops[((size_t)cl * MGL_BATCH_OPCAP + o) * 2u], d = bt.ops[((size_t)cl * MGL_BATCH_OPCAP + o) * 2u + 1u];
@@ -364,37 +397,52 @@ __global__ void __launch_bounds__(256) k_batch_commit(DevCtx c, Base2 b, Control
 	for (uint32_t e = tid; e < nd; e += blockDim.x) b.slab[bt.jpos[j0 + e]] = bt.jnew[j0 + e];
 }
 
-/* touched contexts, ascending (one wavefront) */
-__global__ void __launch_bounds__(64) k_batch_ctxlist(BatchBuf bt, ApplyBuf ab)
+/* per context: where its events go in the bucketed lists (one workgroup: two exclusive scans over the contexts) */
+__global__ void __launch_bounds__(1024) k_batch_scan(BatchBuf bt, ApplyBuf ab)
+{
+	__shared__ uint32_t s_wi[16], s_wr[16], s_bi, s_br;
+	if (bt.hdr[0] != 1u) return;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+	if (tid == 0) { s_bi = 0; s_br = 0; ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0; } /* + the job / span / scratch cursors of k_apply_jobs' lists */
+	__syncthreads();
+	for (uint32_t base = 0; base < bt.nctx; base += blockDim.x) {
+		const uint32_t cx = base + tid;
+		const uint32_t vi = cx < bt.nctx ? bt.cnt_i[cx] : 0u, vr = cx < bt.nctx ? bt.cnt_r[cx] : 0u;
+		uint32_t ii = vi, ir = vr;
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint32_t ti = (uint32_t)__shfl_up((int)ii, o, 64), tr = (uint32_t)__shfl_up((int)ir, o, 64);
+			if ((int)lane >= o) { ii += ti; ir += tr; }
+		}
+		if (lane == 63) { s_wi[wid] = ii; s_wr[wid] = ir; }
+		__syncthreads();
+		uint32_t bi = s_bi, br = s_br;
+		for (uint32_t w = 0; w < wid; w++) { bi += s_wi[w]; br += s_wr[w]; }
+		if (cx < bt.nctx) { bt.off_i[cx] = bi + ii - vi; bt.off_r[cx] = br + ir - vr; }
+		__syncthreads();
+		if (tid == blockDim.x - 1u) { s_bi = bi + ii; s_br = br + ir; }
+		__syncthreads();
+	}
+}
+/* every event of the combined lists into its context's bucket */
+__global__ void __launch_bounds__(256) k_batch_fill(BatchBuf bt, ApplyBuf ab)
 {
 	if (bt.hdr[0] != 1u) return;
-	const uint32_t lane = threadIdx.x;
-	uint32_t nt = 0;
-	for (uint32_t wbase = 0; wbase < 512; wbase += 64) {
-		const uint32_t word = bt.ctxbits[wbase + lane];
-		const uint32_t cntl = (uint32_t)__popc(word);
-		uint32_t incl = cntl;
-		for (int o = 1; o < 64; o <<= 1) {
-			const uint32_t tmp = (uint32_t)__shfl_up((int)incl, o, 64);
-			if ((int)lane >= o) incl += tmp;
+	const uint32_t n_ins = bt.hdr[2], n_rem = bt.hdr[3];
+	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_ins + n_rem; e += gridDim.x * blockDim.x) {
+		if (e < n_ins) {
+			const uint32_t key = ab.ins_key[e], cx = key & 0x7FFFu;
+			const uint32_t at = bt.off_i[cx] + atomicAdd(&bt.cur_i[cx], 1u);
+			bt.bk_ipos[at] = ab.ins_pos[e]; bt.bk_ibit[at] = (uint16_t)(key >> 15); bt.bk_icl[at] = bt.ins_cl[e];
+		} else {
+			const uint32_t r = e - n_ins, cx = ab.rem_key[r];
+			const uint32_t at = bt.off_r[cx] + atomicAdd(&bt.cur_r[cx], 1u);
+			bt.bk_rpos[at] = ab.rem_pos[r]; bt.bk_rcl[at] = bt.rem_cl[r];
 		}
-		uint32_t at = nt + incl - cntl;
-		uint32_t wv = word;
-		while (wv) {
-			const uint32_t bit = (uint32_t)__ffs((int)wv) - 1u;
-			ab.tctx[at++] = (uint16_t)(((wbase + lane) << 5) + bit);
-			wv &= wv - 1u;
-		}
-		nt += (uint32_t)__shfl((int)incl, 63, 64);
-	}
-	if (lane == 0) {
-		bt.hdr[6] = nt;
-		ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0; /* job / span / scratch cursors of k_apply_jobs' lists */
 	}
 }
 
 /* ------------------------------------------------------------------ chains */
-#define MGL_BATCH_THREADS 256u
+#define MGL_BATCH_THREADS 64u /* one wavefront per touched context; a thread per group (<= MGL_BATCH_MAX) */
 
 struct RunOut {
 	uint32_t k_start, k_end; /* old entries [k_start, k_end) are replaced */
@@ -466,9 +514,9 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 		const uint32_t nxt = ipos < rpos ? ipos : rpos;
 		if (p == bp && nxt > bpos) {
 			/* re-joined at old entry k (which stays), nothing changes at it.  The run ends here -- unless the context's next
-			 * change belongs to the cluster the run is in: a cluster's events in one context can come in several bunches
-			 * (a match at 246 behind literals re-priced up to 243), and a group has one run; the entries in between are
-			 * written again as they are (same probability: no cost change) */
+			 * change belongs to the group the run is in (a group's events can come in bunches a few bytes apart: a match at
+			 * 246 behind literals re-priced up to 243), and a group has one run; the entries in between are written again as
+			 * they are (same probability: no cost change) */
 			const uint32_t nxt_cl = nxt == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
 			if (nxt_cl != last_cl) { r.hi = bpos; break; }
 		}
@@ -497,86 +545,64 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Base2 b, Control* ctl, BatchBuf bt, ApplyBuf ab)
 {
 	__shared__ uint16_t T[2048];
-	__shared__ uint32_t s_ipos[MGL_BATCH_SUB], s_rpos[MGL_BATCH_SUB];
+	__shared__ uint32_t s_ipos[MGL_BATCH_SUB], s_rpos[MGL_BATCH_SUB], s_upos[MGL_BATCH_SUB];
 	__shared__ uint16_t s_ibit[MGL_BATCH_SUB];
 	__shared__ uint8_t s_icl[MGL_BATCH_SUB], s_rcl[MGL_BATCH_SUB];
-	__shared__ uint32_t s_wcount[MGL_BATCH_THREADS / 64];
 	/* groups (one per cluster that touches the context, ascending) and the runs that start at them */
 	__shared__ uint8_t s_gcl[MGL_BATCH_MAX + 1];
 	__shared__ uint32_t s_gi[MGL_BATCH_MAX + 1], s_gr[MGL_BATCH_MAX + 1]; /* first inserted / removed event of the group */
-	__shared__ uint32_t s_clfirst_i[MGL_BATCH_MAX], s_clfirst_r[MGL_BATCH_MAX];
 	__shared__ RunOut s_run[MGL_BATCH_MAX];
 	__shared__ uint32_t s_hlist[MGL_BATCH_MAX], s_hspan[MGL_BATCH_MAX + 1];
 	__shared__ int32_t s_hdelta[MGL_BATCH_MAX + 1]; /* length change accumulated up to and including head h */
-	__shared__ uint32_t s_ni, s_nr, s_ng, s_nh, s_fail, s_span_base, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
+	__shared__ uint32_t s_ng, s_nh, s_fail, s_span_base, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
 	if (bt.hdr[0] != 1u || bt.hdr[4]) return;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+	/* one workgroup (one wavefront) per context: most have nothing to do */
+	const uint32_t cx = blockIdx.x;
+	if (cx >= bt.nctx) return;
+	const uint32_t ni = bt.cnt_i[cx], nr = bt.cnt_r[cx];
+	if (ni == 0 && nr == 0) return;
+	const uint32_t tid = threadIdx.x;
+	if (ni > MGL_BATCH_SUB || nr > MGL_BATCH_SUB) { if (tid == 0) ctl->apply_failed = 1; return; }
 	for (uint32_t i = tid; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
-	const uint32_t n_ins = bt.hdr[2], n_rem = bt.hdr[3], nt = bt.hdr[6], ncl = bt.hdr[1];
 	long long my_cost = 0; /* thread 0 sums the context's runs */
-	for (uint32_t ti = blockIdx.x; ti < nt; ti += gridDim.x) {
-		const uint32_t cx = ab.tctx[ti];
-		__syncthreads();
-		if (tid == 0) { s_ni = 0; s_nr = 0; s_fail = 0; }
-		for (uint32_t i = tid; i < MGL_BATCH_MAX; i += blockDim.x) { s_clfirst_i[i] = 0xFFFFFFFFu; s_clfirst_r[i] = 0xFFFFFFFFu; }
-		__syncthreads();
-		/* ---- 1. this context's events, order (= position order) preserved */
+	{
+		if (tid == 0) s_fail = 0;
+		/* ---- 1. this context's events, by position (its bucket holds them in any order; positions are distinct within a list) */
 		for (int pass = 0; pass < 2; pass++) {
-			const uint32_t m = pass == 0 ? n_ins : n_rem;
-			for (uint32_t base = 0; base < m; base += MGL_BATCH_THREADS) {
-				const uint32_t e = base + tid;
-				bool hit = false;
-				uint32_t key = 0, pos = 0, ecl = 0;
-				if (e < m) {
-					key = pass == 0 ? ab.ins_key[e] : ab.rem_key[e];
-					hit = (key & 0x7FFFu) == cx;
-					if (hit) { pos = pass == 0 ? ab.ins_pos[e] : ab.rem_pos[e]; ecl = pass == 0 ? bt.ins_cl[e] : bt.rem_cl[e]; }
-				}
-				const unsigned long long mask = __ballot(hit);
-				if (lane == 0) s_wcount[wid] = (uint32_t)__popcll(mask);
-				__syncthreads();
-				uint32_t before = pass == 0 ? s_ni : s_nr;
-				for (uint32_t w = 0; w < wid; w++) before += s_wcount[w];
-				const uint32_t idx = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-				if (hit) {
-					if (idx < MGL_BATCH_SUB) {
-						if (pass == 0) { s_ipos[idx] = pos; s_ibit[idx] = (uint16_t)(key >> 15); s_icl[idx] = (uint8_t)ecl; atomicMin(&s_clfirst_i[ecl], idx); }
-						else { s_rpos[idx] = pos; s_rcl[idx] = (uint8_t)ecl; atomicMin(&s_clfirst_r[ecl], idx); }
-					} else s_fail = 1;
-				}
-				__syncthreads();
-				if (tid == 0) {
-					uint32_t tot = 0;
-					for (uint32_t w = 0; w < MGL_BATCH_THREADS / 64; w++) tot += s_wcount[w];
-					if (pass == 0) s_ni += tot; else s_nr += tot;
-				}
-				__syncthreads();
+			const uint32_t m = pass == 0 ? ni : nr, o = pass == 0 ? bt.off_i[cx] : bt.off_r[cx];
+			const uint32_t* gp = pass == 0 ? bt.bk_ipos + o : bt.bk_rpos + o;
+			__syncthreads();
+			for (uint32_t e = tid; e < m; e += blockDim.x) s_upos[e] = gp[e];
+			__syncthreads();
+			for (uint32_t e = tid; e < m; e += blockDim.x) {
+				const uint32_t pos = s_upos[e];
+				uint32_t r = 0;
+				for (uint32_t x = 0; x < m; x++) r += s_upos[x] < pos ? 1u : 0u;
+				if (pass == 0) { s_ipos[r] = pos; s_ibit[r] = bt.bk_ibit[o + e]; }
+				else s_rpos[r] = pos;
 			}
 		}
-		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
-		/* ---- 2. groups: the clusters that touch this context, ascending; where each one's events begin in the two lists */
+		__syncthreads();
+		/* ---- 2. groups: the context's events (both lists, by position) in bunches -- a new one wherever the next event lies
+		 * more than MGL_BATCH_GAP positions on (at most MGL_BATCH_MAX of them: the last one takes the rest).  Every group
+		 * starts a run; which partition is chosen does not matter for the result (runs that have not re-joined the old
+		 * trajectory by the next group's first event go on through it), only for how much runs in parallel and how many
+		 * unchanged entries between two bunches of one group are written again. */
 		if (tid == 0) {
-			uint32_t ng = 0, ci = 0, cr = 0;
-			for (uint32_t q = 0; q < ncl; q++) {
-				const bool hi = s_clfirst_i[q] != 0xFFFFFFFFu, hr = s_clfirst_r[q] != 0xFFFFFFFFu;
-				if (!hi && !hr) continue;
-				if (hi) ci = s_clfirst_i[q];
-				if (hr) cr = s_clfirst_r[q];
-				/* a cluster without inserted (removed) events starts where the next cluster's begin */
-				s_gcl[ng] = (uint8_t)q; s_gi[ng] = hi ? ci : 0xFFFFFFFFu; s_gr[ng] = hr ? cr : 0xFFFFFFFFu;
-				ng++;
+			uint32_t ng = 0, i = 0, r = 0, prev = 0;
+			while (i < ni || r < nr) {
+				const uint32_t pi = i < ni ? s_ipos[i] : MGL_POS_INF, pr = r < nr ? s_rpos[r] : MGL_POS_INF;
+				const uint32_t pos = pi < pr ? pi : pr;
+				if (ng == 0 || (pos - prev > MGL_BATCH_GAP && ng < MGL_BATCH_MAX)) { s_gcl[ng] = (uint8_t)ng; s_gi[ng] = i; s_gr[ng] = r; ng++; }
+				if (pi == pos) { s_icl[i] = (uint8_t)(ng - 1u); i++; }
+				if (pr == pos) { s_rcl[r] = (uint8_t)(ng - 1u); r++; }
+				prev = pos;
 			}
-			/* fill the gaps backwards: first event at or after the group's range in each list */
-			uint32_t nxi = s_ni, nxr = s_nr;
-			for (uint32_t g = ng; g-- > 0;) {
-				if (s_gi[g] == 0xFFFFFFFFu) s_gi[g] = nxi; else nxi = s_gi[g];
-				if (s_gr[g] == 0xFFFFFFFFu) s_gr[g] = nxr; else nxr = s_gr[g];
-			}
-			s_gcl[ng] = 0xFF; s_gi[ng] = s_ni; s_gr[ng] = s_nr;
+			s_gcl[ng] = 0xFF; s_gi[ng] = ni; s_gr[ng] = nr;
 			s_ng = ng;
 		}
 		__syncthreads();
-		const uint32_t ng = s_ng, ni = s_ni, nr = s_nr;
+		const uint32_t ng = s_ng;
 		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
 		const uint32_t* cpos = b.ch_pos + off;
 		const uint16_t* cev = b.ch_ev + off;
@@ -614,7 +640,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			s_fail = fail ? 1u : 0u;
 		}
 		__syncthreads();
-		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
 		const uint32_t nh = s_nh, spb = s_span_base, noff = s_newoff, maxd = s_maxd;
 		const bool moved = noff != off;
 		/* ---- 5. the runs that count write their entries */
@@ -652,7 +678,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			if (s_job_b + jb > ab.job_cap || s_job_c + jc > ab.job_cap || s_scr_base + scr > ab.scratch_cap) s_fail = 1;
 		}
 		__syncthreads();
-		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; continue; }
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
 		if (tid == 0) {
 			uint32_t jb = s_job_b, jc = s_job_c, scr = s_scr_base;
 			if (moved) {
@@ -686,25 +712,52 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			b.ch_len[cx] = s_newlen;
 			if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
 		}
-		/* ---- 7. dense checkpoints: this context's value wherever its trajectory changed */
-		for (uint32_t h = 0; h < nh; h++) {
-			const RunOut& r = s_run[s_hlist[h]];
-			const uint32_t lo = r.lo, hi = r.hi;
-			const uint32_t first = spb + s_hspan[h], last = first + r.ns;
-			const uint32_t ck_lo = (lo > MGL_MAX_MATCH ? lo - MGL_MAX_MATCH : 0u) >> MGL_CK2_SHIFT;
-			const uint32_t ck_hi = hi == MGL_POS_INF ? b.nck : ((hi >> MGL_CK2_SHIFT) + 1u < b.nck ? (hi >> MGL_CK2_SHIFT) + 1u : b.nck);
-			__syncthreads(); /* the run's entries are in the span area (step 5, another thread's stores) */
-			for (uint32_t ck = ck_lo + tid; ck < ck_hi; ck += blockDim.x) {
-				const uint32_t P = ckpt_boundary(b, ck); /* on the NEW walk (the bitmaps are committed); MGL_POS_INF: the final model */
-				if (P <= lo || P > hi) continue;
-				uint32_t a = first, z = last;
-				while (a < z) { const uint32_t mid = (a + z) >> 1; if (ab.span_pos[mid] < P) a = mid + 1; else z = mid; }
-				const uint16_t v = a < last ? (uint16_t)(ab.span_ev[a] & 0x7FFu) : (uint16_t)r.end_p;
-				b.ck_probs[(size_t)ck * b.ck_elems + cx] = v;
-			}
+		/* ---- 7. the runs go on a list: k_batch_ckpt patches this context's value in the dense checkpoints along each of them
+		 * (a run of a rare context reaches over hundreds of kilobytes, thousands of rows: a job for more than one wavefront) */
+		__syncthreads();
+		if (tid < nh) {
+			const RunOut& r = s_run[s_hlist[tid]];
+			const uint32_t at = atomicAdd(&bt.hdr[8], 1u);
+			if (at < bt.runs_cap) {
+				bt.runs[2u * at] = make_uint4(cx, r.lo, r.hi, spb + s_hspan[tid]);
+				bt.runs[2u * at + 1u] = make_uint4(r.ns, r.end_p, 0u, 0u);
+			} else ctl->apply_failed = 1;
 		}
 	}
 	if (tid == 0 && my_cost) atomicAdd((unsigned long long*)&bt.acc[0], (unsigned long long)my_cost);
+}
+
+/* dense checkpoints: along every run, the context's value wherever its trajectory changed (one workgroup per run) */
+#define MGL_BATCH_CK_SPAN 2048u
+__global__ void __launch_bounds__(256) k_batch_ckpt(Base2 b, const Control* ctl, BatchBuf bt, ApplyBuf ab)
+{
+	__shared__ uint32_t s_pos[MGL_BATCH_CK_SPAN];
+	__shared__ uint16_t s_ev[MGL_BATCH_CK_SPAN];
+	if (bt.hdr[0] != 1u || bt.hdr[4] || ctl->apply_failed) return;
+	const uint32_t nruns = bt.hdr[8] < bt.runs_cap ? bt.hdr[8] : bt.runs_cap;
+	for (uint32_t ri = blockIdx.x; ri < nruns; ri += gridDim.x) {
+		const uint4 r0 = bt.runs[2u * ri], r1 = bt.runs[2u * ri + 1u];
+		const uint32_t cx = r0.x, lo = r0.y, hi = r0.z, first = r0.w, ns = r1.x, end_p = r1.y;
+		const bool in_lds = ns <= MGL_BATCH_CK_SPAN;
+		__syncthreads();
+		if (in_lds) for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) { s_pos[i] = ab.span_pos[first + i]; s_ev[i] = ab.span_ev[first + i]; }
+		__syncthreads();
+		/* a boundary can lie behind a packet that starts up to 272 bytes before lo */
+		const uint32_t ck_lo = (lo > MGL_MAX_MATCH ? lo - MGL_MAX_MATCH : 0u) >> MGL_CK2_SHIFT;
+		const uint32_t ck_hi = hi == MGL_POS_INF ? b.nck : ((hi >> MGL_CK2_SHIFT) + 1u < b.nck ? (hi >> MGL_CK2_SHIFT) + 1u : b.nck);
+		/* blockIdx.y: the run's rows in gridDim.y slices (a run of a rare context reaches over thousands of rows) */
+		const uint32_t per = (ck_hi - ck_lo + gridDim.y - 1u) / gridDim.y;
+		const uint32_t my_lo = ck_lo + blockIdx.y * per, my_hi = (my_lo + per) < ck_hi ? (my_lo + per) : ck_hi;
+		for (uint32_t ck = my_lo + threadIdx.x; ck < my_hi; ck += blockDim.x) {
+			const uint32_t P = ckpt_boundary(b, ck); /* on the NEW walk (the bitmaps are committed); MGL_POS_INF: the final model */
+			if (P <= lo || P > hi) continue;      /* the value there is the old one */
+			/* probability before the first new entry of the run at or after P */
+			uint32_t a = 0, z = ns;
+			while (a < z) { const uint32_t mid = (a + z) >> 1; if ((in_lds ? s_pos[mid] : ab.span_pos[first + mid]) < P) a = mid + 1; else z = mid; }
+			const uint16_t v = a < ns ? (uint16_t)((in_lds ? s_ev[a] : ab.span_ev[first + a]) & 0x7FFu) : (uint16_t)end_p;
+			b.ck_probs[(size_t)ck * b.ck_elems + cx] = v;
+		}
+	}
 }
 
 /* totals of a batch accept into Control: the new base's exact cost, its packet count */

@@ -25,6 +25,9 @@ while prepare != 0 and done < (prepare if prepare > 0 else PREPARE_CAP[cfg]):
     print("prepare", done, {k: p[k] for k in ("accepted", "bulk_steps", "best_cost", "packets")}, flush=True)
     if prepare < 0 and p["bulk_steps"] * 16 <= p["steps"]:
         break
+if os.environ.get("MGL_RUN_ACCEPT"):  # the accept mode of the measured steps (default: the library's, auto)
+    sa.set_accept_mode(os.environ["MGL_RUN_ACCEPT"])
 st = sa.run(steps)
+print("batch accepts / fallbacks", sa.batch_counters())
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})
 sa.close()

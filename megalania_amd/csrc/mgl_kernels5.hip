@@ -41,6 +41,7 @@
 #define MGL_BATCH_EVCAP 4096u  /* inserted / removed events staged per cluster */
 #define MGL_BATCH_OPCAP 2048u  /* bitmap / state-record ops per cluster */
 #define MGL_BATCH_SUB 1024u    /* events of one kind per context */
+#define MGL_BATCH_RES 256u     /* entries of the span area every run gets to begin with */
 #define MGL_BATCH_GAP 32u      /* events of a context further apart than this start a group of their own */
 #define MGL_BATCH_ALLOC (MGL_BATCH_MAX * MGL_BATCH_EVCAP) /* entries of the combined event lists (ApplyBuf lists are allocated this long) */
 
@@ -461,9 +462,9 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
                                             const uint32_t* s_ipos, const uint16_t* s_ibit, const uint8_t* s_icl, uint32_t ni,
                                             const uint32_t* s_rpos, const uint8_t* s_rcl, uint32_t nr,
                                             uint32_t ii, uint32_t ri, const uint8_t* s_gcl, uint32_t g,
-                                            uint32_t* span_pos, uint16_t* span_ev, uint32_t at)
+                                            uint32_t* span_pos, uint16_t* span_ev, uint32_t at, uint32_t wcap)
 {
-	RunOut r;
+	RunOut r; /* (WRITE: only the first `wcap` new entries are written; the sizes are exact whatever it is) */
 	uint32_t ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF, rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
 	const uint32_t x0 = ipos < rpos ? ipos : rpos;
 	uint32_t k = chain_lower_bound(cpos, len, x0);
@@ -496,11 +497,41 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 	uint32_t ns = 0;
 	for (;;) {
 		chunk(k);
+		{
+			/* Most of a run is its tail: no change of this context anywhere near, the old entries are re-priced one after the
+			 * other until the probability has re-joined theirs.  When the next change lies behind everything this chunk holds,
+			 * its entries go through a loop unrolled over the eight registers (no merge logic, no register picked at run time). */
+			const uint32_t nxt0 = ipos < rpos ? ipos : rpos;
+			const uint32_t lastp = c_pb.w; /* positions ascend: the chunk's last one bounds them all (the sentinel's is infinity) */
+			if (c_base + 8u <= len && nxt0 > lastp) { /* (a chunk that holds the sentinel, and whatever lies behind it, goes the slow way) */
+				const uint32_t pp[8] = { c_pa.x, c_pa.y, c_pa.z, c_pa.w, c_pb.x, c_pb.y, c_pb.z, c_pb.w };
+				const uint32_t ew[4] = { c_ev.x, c_ev.y, c_ev.z, c_ev.w };
+				const uint32_t e0 = k & 7u;
+				bool done = false;
+#pragma unroll
+				for (uint32_t e = 0; e < 8; e++) {
+					if (e < e0 || done) continue;
+					const uint32_t ev = (ew[e >> 1] >> ((e & 1u) * 16u)) & 0xFFFFu;
+					const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+					if (p == bp) {
+						const uint32_t nxt_cl = nxt0 == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
+						if (nxt_cl != last_cl) { r.hi = pp[e]; done = true; continue; } /* re-joined: the run ends at old entry k */
+					}
+					if (WRITE && ns < wcap) { span_pos[at + ns] = pp[e]; span_ev[at + ns] = (uint16_t)((bb << 15) | p); }
+					ns++;
+					dc += (long long)T[bb ? 2048u - p : p] - (long long)T[bb ? 2048u - bp : bp];
+					p = mgl_prob_update(p, bb);
+					k++;
+				}
+				if (done) break;
+				continue;
+			}
+		}
 		const uint32_t bpos = k > len ? MGL_POS_INF : pos_at(k); /* entry `len` is the sentinel (position = infinity) */
 		if (ipos < bpos) { /* an inserted event comes first */
 			const uint32_t bit = s_ibit[ii];
 			last_cl = s_icl[ii];
-			if (WRITE) { span_pos[at + ns] = ipos; span_ev[at + ns] = (uint16_t)((bit << 15) | p); }
+			if (WRITE && ns < wcap) { span_pos[at + ns] = ipos; span_ev[at + ns] = (uint16_t)((bit << 15) | p); }
 			ns++;
 			dc += T[bit ? 2048u - p : p];
 			p = mgl_prob_update(p, bit);
@@ -526,7 +557,7 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 			ri++;
 			rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
 		} else { /* it stays, priced at the new probability */
-			if (WRITE) { span_pos[at + ns] = bpos; span_ev[at + ns] = (uint16_t)((bb << 15) | p); }
+			if (WRITE && ns < wcap) { span_pos[at + ns] = bpos; span_ev[at + ns] = (uint16_t)((bb << 15) | p); }
 			ns++;
 			dc += T[bb ? 2048u - p : p];
 			p = mgl_prob_update(p, bb);
@@ -544,7 +575,7 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 
 __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Base2 b, Control* ctl, BatchBuf bt, ApplyBuf ab)
 {
-	__shared__ uint16_t T[2048];
+	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
 	__shared__ uint32_t s_ipos[MGL_BATCH_SUB], s_rpos[MGL_BATCH_SUB], s_upos[MGL_BATCH_SUB];
 	__shared__ uint16_t s_ibit[MGL_BATCH_SUB];
 	__shared__ uint8_t s_icl[MGL_BATCH_SUB], s_rcl[MGL_BATCH_SUB];
@@ -552,9 +583,9 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 	__shared__ uint8_t s_gcl[MGL_BATCH_MAX + 1];
 	__shared__ uint32_t s_gi[MGL_BATCH_MAX + 1], s_gr[MGL_BATCH_MAX + 1]; /* first inserted / removed event of the group */
 	__shared__ RunOut s_run[MGL_BATCH_MAX];
-	__shared__ uint32_t s_hlist[MGL_BATCH_MAX], s_hspan[MGL_BATCH_MAX + 1];
+	__shared__ uint32_t s_hlist[MGL_BATCH_MAX], s_hspan[MGL_BATCH_MAX + 1], s_gat[MGL_BATCH_MAX], s_hjb[MGL_BATCH_MAX], s_hjc[MGL_BATCH_MAX], s_hscr[MGL_BATCH_MAX];
 	__shared__ int32_t s_hdelta[MGL_BATCH_MAX + 1]; /* length change accumulated up to and including head h */
-	__shared__ uint32_t s_ng, s_nh, s_fail, s_span_base, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
+	__shared__ uint32_t s_ng, s_nh, s_fail, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
 	if (bt.hdr[0] != 1u || bt.hdr[4]) return;
 	/* one workgroup (one wavefront) per context: most have nothing to do */
 	const uint32_t cx = blockIdx.x;
@@ -563,7 +594,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 	if (ni == 0 && nr == 0) return;
 	const uint32_t tid = threadIdx.x;
 	if (ni > MGL_BATCH_SUB || nr > MGL_BATCH_SUB) { if (tid == 0) ctl->apply_failed = 1; return; }
-	for (uint32_t i = tid; i < 2048; i += blockDim.x) T[i] = c.cost_tbl[i];
+	for (uint32_t i = tid; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
 	long long my_cost = 0; /* thread 0 sums the context's runs */
 	{
 		if (tid == 0) s_fail = 0;
@@ -606,17 +637,25 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
 		const uint32_t* cpos = b.ch_pos + off;
 		const uint16_t* cev = b.ch_ev + off;
-		/* ---- 3. every group starts a run (sizes only) ... */
-		if (tid < ng)
-			s_run[tid] = batch_run<false>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, nullptr, nullptr, 0u);
+		/* ---- 3. every group starts a run, writing its new entries into MGL_BATCH_RES entries of the span area taken for it
+		 * (most runs fit: a perturbed probability re-joins the old trajectory after about a hundred events; one that does not is
+		 * run again in step 5, into a place of its size) ... */
+		if (tid < ng) {
+			const uint32_t at = atomicAdd(&ab.hdr[6], MGL_BATCH_RES);
+			s_gat[tid] = at;
+			if (at + MGL_BATCH_RES > ab.span_cap) s_fail = 1;
+			else s_run[tid] = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, ab.span_pos, ab.span_ev, at, MGL_BATCH_RES);
+		}
 		__syncthreads();
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
 		/* ---- 4. ... the ones that count begin where the previous one ended */
 		if (tid == 0) {
-			uint32_t nh = 0, sp = 0, maxd = 0;
+			uint32_t nh = 0, maxd = 0;
 			int32_t d = 0;
 			for (uint32_t g = 0; g < ng; g = s_run[g].last_group + 1u) {
-				s_hlist[nh] = g; s_hspan[nh] = sp;
-				sp += s_run[g].ns + (s_run[g].uncoupled ? 1u : 0u); /* + the new sentinel */
+				const uint32_t spn = s_run[g].ns + (s_run[g].uncoupled ? 1u : 0u); /* + the new sentinel */
+				s_hlist[nh] = g;
+				s_hspan[nh] = spn <= MGL_BATCH_RES ? s_gat[g] : 0xFFFFFFFFu; /* where the run's entries are (absolute); 0xFFFFFFFF: to be written in step 5 */
 				d += (int32_t)s_run[g].ns - (int32_t)(s_run[g].k_end - s_run[g].k_start);
 				s_hdelta[nh] = d;
 				const uint32_t adl = (uint32_t)(d < 0 ? -d : d);
@@ -624,7 +663,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 				my_cost += s_run[g].dcost;
 				nh++;
 			}
-			s_hspan[nh] = sp; s_nh = nh; s_maxd = maxd;
+			s_nh = nh; s_maxd = maxd;
 			const uint32_t newlen = (uint32_t)((int32_t)len + d); /* (a run that ends at the sentinel un-coupled replaces everything up to it, and writes a new one) */
 			s_newlen = newlen;
 			uint32_t newoff = off, newcap = cap;
@@ -635,34 +674,45 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 				if (newoff + newcap > b.pool_cap) fail = true;
 			}
 			s_newoff = newoff; s_newcap = newcap;
-			s_span_base = atomicAdd(&ab.hdr[6], sp);
-			if (s_span_base + sp > ab.span_cap) fail = true;
 			s_fail = fail ? 1u : 0u;
 		}
 		__syncthreads();
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
-		const uint32_t nh = s_nh, spb = s_span_base, noff = s_newoff, maxd = s_maxd;
+		const uint32_t nh = s_nh, noff = s_newoff, maxd = s_maxd;
 		const bool moved = noff != off;
-		/* ---- 5. the runs that count write their entries */
+		/* ---- 5. a run that counts and did not fit its place: again, into one of its size; the new sentinel behind a run that
+		 * ran into the old one un-coupled */
 		if (tid < nh) {
 			const uint32_t g = s_hlist[tid];
-			const RunOut r = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, spb + s_hspan[tid]);
-			if (r.uncoupled) { ab.span_pos[spb + s_hspan[tid] + r.ns] = MGL_POS_INF; ab.span_ev[spb + s_hspan[tid] + r.ns] = (uint16_t)r.end_p; }
+			const RunOut& r0 = s_run[g];
+			const uint32_t spn = r0.ns + (r0.uncoupled ? 1u : 0u);
+			uint32_t at = s_hspan[tid];
+			if (at == 0xFFFFFFFFu) {
+				at = atomicAdd(&ab.hdr[6], spn);
+				if (at + spn > ab.span_cap) s_fail = 1;
+				else {
+					s_hspan[tid] = at;
+					(void)batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, at, spn);
+				}
+			}
+			if (!s_fail && r0.uncoupled) { ab.span_pos[at + r0.ns] = MGL_POS_INF; ab.span_ev[at + r0.ns] = (uint16_t)r0.end_p; }
 		}
+		__syncthreads();
+		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
 		/* ---- 6. the rewrite as copy jobs.  Pieces in chain order: [prefix] run 0, stretch 0, run 1, stretch 1, ... ; stretch h
 		 * = old entries [k_end(h), k_start(h + 1)) (the last one runs to the sentinel, included) and moves by the length change
 		 * accumulated up to run h.  In place: a stretch that does not move is left alone; one that moves goes in chunks that
 		 * are loaded whole, then stored (MGL_SPACE_SHIFT2), their first and last `maxd` entries -- all that the stores of
 		 * another piece can reach before the chunk is loaded -- coming from copies taken in pass B.  A chain that moves to a
-		 * new slot is simply copied piece by piece. */
-		__syncthreads();
-		/* count the jobs, reserve, then emit with the same loop (two sweeps over at most MGL_BATCH_MAX + 1 pieces per thread-0) */
+		 * new slot is simply copied piece by piece.  Thread 0 counts the jobs of every piece and takes their places in the
+		 * lists; all threads write them (a chain of a million entries is hundreds of chunks). */
 		if (tid == 0) {
 			uint32_t jb = 0, jc = 0, scr = 0;
 			if (moved) jb += (s_run[s_hlist[0]].k_start + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK; /* prefix to the new slot */
 			for (uint32_t h = 0; h < nh; h++) {
 				const RunOut& r = s_run[s_hlist[h]];
 				const uint32_t spn = r.ns + (r.uncoupled ? 1u : 0u);
+				s_hjb[h] = jb; s_hjc[h] = jc; s_hscr[h] = scr;
 				jc += (spn + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK;
 				if (r.uncoupled) continue; /* nothing behind it */
 				const uint32_t s0 = r.k_end, s1 = h + 1u < nh ? s_run[s_hlist[h + 1u]].k_start : len + 1u;
@@ -679,38 +729,49 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		}
 		__syncthreads();
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
-		if (tid == 0) {
-			uint32_t jb = s_job_b, jc = s_job_c, scr = s_scr_base;
+		{
+			const uint32_t jb0 = s_job_b, jc0 = s_job_c, scr0 = s_scr_base;
+			const uint32_t pre = moved ? (s_run[s_hlist[0]].k_start + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK : 0u; /* the prefix's jobs lead pass B's list */
 			if (moved) {
 				const uint32_t k0 = s_run[s_hlist[0]].k_start;
-				for (uint32_t at = 0; at < k0; at += MGL_JOB_CHUNK)
-					ab.jobs_b[jb++] = make_uint4(off + at, noff + at, (k0 - at) < MGL_JOB_CHUNK ? (k0 - at) : MGL_JOB_CHUNK, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8));
+				for (uint32_t ci = tid; ci < pre; ci += blockDim.x) {
+					const uint32_t at = ci * MGL_JOB_CHUNK;
+					ab.jobs_b[jb0 + ci] = make_uint4(off + at, noff + at, (k0 - at) < MGL_JOB_CHUNK ? (k0 - at) : MGL_JOB_CHUNK, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8));
+				}
 			}
+			(void)pre;
 			for (uint32_t h = 0; h < nh; h++) {
 				const RunOut& r = s_run[s_hlist[h]];
 				const int32_t dprev = h ? s_hdelta[h - 1u] : 0;
 				const uint32_t spn = r.ns + (r.uncoupled ? 1u : 0u);
 				const uint32_t dst0 = (uint32_t)((int32_t)r.k_start + dprev);
-				for (uint32_t at = 0; at < spn; at += MGL_JOB_CHUNK)
-					ab.jobs_c[jc++] = make_uint4(spb + s_hspan[h] + at, noff + dst0 + at, (spn - at) < MGL_JOB_CHUNK ? (spn - at) : MGL_JOB_CHUNK, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8));
+				const uint32_t nsp = (spn + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK;
+				for (uint32_t ci = tid; ci < nsp; ci += blockDim.x) {
+					const uint32_t at = ci * MGL_JOB_CHUNK;
+					ab.jobs_c[jc0 + s_hjc[h] + ci] = make_uint4(s_hspan[h] + at, noff + dst0 + at, (spn - at) < MGL_JOB_CHUNK ? (spn - at) : MGL_JOB_CHUNK, MGL_SPACE_SPAN | (MGL_SPACE_CHAIN << 8));
+				}
 				if (r.uncoupled) continue;
 				const uint32_t s0 = r.k_end, s1 = h + 1u < nh ? s_run[s_hlist[h + 1u]].k_start : len + 1u;
 				const uint32_t cnt = s1 - s0;
 				const int32_t d = s_hdelta[h];
 				if (cnt == 0 || (!moved && d == 0)) continue;
-				for (uint32_t at = 0; at < cnt; at += MGL_JOB_CHUNK) {
+				const uint32_t nchunks = (cnt + MGL_JOB_CHUNK - 1u) / MGL_JOB_CHUNK;
+				const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+				for (uint32_t ci = tid; ci < nchunks; ci += blockDim.x) {
+					const uint32_t at = ci * MGL_JOB_CHUNK;
 					const uint32_t n1 = (cnt - at) < MGL_JOB_CHUNK ? (cnt - at) : MGL_JOB_CHUNK;
-					if (moved) { ab.jobs_c[jc++] = make_uint4(off + s0 + at, (uint32_t)((int32_t)(noff + s0 + at) + d), n1, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8)); continue; }
+					if (moved) { ab.jobs_c[jc0 + s_hjc[h] + nsp + ci] = make_uint4(off + s0 + at, (uint32_t)((int32_t)(noff + s0 + at) + d), n1, MGL_SPACE_CHAIN | (MGL_SPACE_CHAIN << 8)); continue; }
 					const uint32_t sl = maxd < n1 ? maxd : n1; /* a chunk shorter than maxd is saved whole (both slivers overlap) */
-					ab.jobs_b[jb++] = make_uint4(off + s0 + at, scr, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
-					ab.jobs_b[jb++] = make_uint4(off + s0 + at + n1 - sl, scr + maxd, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
-					const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
-					ab.jobs_c[jc++] = make_uint4(off + s0 + at, scr, n1, MGL_SPACE_SHIFT2 | (ad << 8) | (d < 0 ? 1u << 20 : 0u) | (maxd << 21));
-					scr += 2u * maxd;
+					const uint32_t scr = scr0 + s_hscr[h] + 2u * maxd * ci;
+					ab.jobs_b[jb0 + s_hjb[h] + 2u * ci] = make_uint4(off + s0 + at, scr, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
+					ab.jobs_b[jb0 + s_hjb[h] + 2u * ci + 1u] = make_uint4(off + s0 + at + n1 - sl, scr + maxd, sl, MGL_SPACE_CHAIN | (MGL_SPACE_SCRATCH << 8));
+					ab.jobs_c[jc0 + s_hjc[h] + nsp + ci] = make_uint4(off + s0 + at, scr, n1, MGL_SPACE_SHIFT2 | (ad << 8) | (d < 0 ? 1u << 20 : 0u) | (maxd << 21));
 				}
 			}
-			b.ch_len[cx] = s_newlen;
-			if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
+			if (tid == 0) {
+				b.ch_len[cx] = s_newlen;
+				if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
+			}
 		}
 		/* ---- 7. the runs go on a list: k_batch_ckpt patches this context's value in the dense checkpoints along each of them
 		 * (a run of a rare context reaches over hundreds of kilobytes, thousands of rows: a job for more than one wavefront) */
@@ -719,7 +780,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			const RunOut& r = s_run[s_hlist[tid]];
 			const uint32_t at = atomicAdd(&bt.hdr[8], 1u);
 			if (at < bt.runs_cap) {
-				bt.runs[2u * at] = make_uint4(cx, r.lo, r.hi, spb + s_hspan[tid]);
+				bt.runs[2u * at] = make_uint4(cx, r.lo, r.hi, s_hspan[tid]);
 				bt.runs[2u * at + 1u] = make_uint4(r.ns, r.end_p, 0u, 0u);
 			} else ctl->apply_failed = 1;
 		}

@@ -360,6 +360,23 @@ def main():
         if cs["sim_launches"]:
             counted = dict(steps=cs["steps"], launches=cs["sim_launches"], bytes=cs["sim_bytes_counted"], evaluations=cs["evaluations"],
                            ms=cs["gpu_ms_sim"])
+    # the same state in the library's default accept mode (auto: steps take every compatible improving neighbour and patch
+    # them in at once, or rebuild when they are many), for the same number of steps: what a user of the defaults gets
+    default_mode = None
+    if rank == 0:
+        sa.set_accept_mode("auto")
+        sa.run(4)
+        ba0 = sa.batch_counters()
+        t1 = time.perf_counter()
+        ds = sa.run(args.steps)
+        t1 = time.perf_counter() - t1
+        ba1 = sa.batch_counters()
+        default_mode = {"evals_per_s": ds["evaluations"] / t1, "ms_per_step": t1 / max(1, ds["steps"]) * 1e3, "steps": ds["steps"],
+                        "moves_per_step": ds["accepted"] / max(1, ds["steps"]), "bulk_steps": ds["bulk_steps"],
+                        "steps_patched_in_place": ba1[0] - ba0[0], "steps_rebuilt": ds["bulk_steps"] - (ba1[0] - ba0[0]),
+                        "moves_per_s": ds["accepted"] / t1,
+                        "single_mode_moves_per_s": st["accepted"] / elapsed if elapsed > 0 else None,
+                        "note": "accept mode auto on the state the timed steps left; `value` above is accept mode single (one move per step at most)"}
     evals, walked = st["evaluations"], st["packets_evaluated"]
     if dist is not None:
         import torch
@@ -457,6 +474,8 @@ def main():
                       "fallback_neighbours": st["fallback_neighbours"],
                       "second_pass_neighbours": st["second_pass_neighbours"]},
         }
+        if default_mode:
+            out["default_mode"] = default_mode
         if exchange:
             out["exchange"] = exchange
         if prep:

@@ -78,6 +78,11 @@ typedef struct {
 
 #define MGL_F_PROFILE 4u  /* diagnostic: per-phase cycle counters in the neighbour kernels */
 #define MGL_F_SERIAL_BUILD 16u /* derive the base structures with the one-wavefront builder only (diagnostic) */
+#define MGL_F_POSITION_TARGETS 32u /* neighbour j's target from up to 32 uniform position draws (the first that is a packet start)
+                              * instead of the default: a packet of the j-th of K equal slices of the walk's packets, by ordinal.
+                              * Both make every packet equally likely (packet_slab_neighbour.c:162-163 draws a packet ordinal);
+                              * the default keeps the K targets of one step apart, so that fewer improving neighbours of a step
+                              * overlap and a bulk step takes 95 % of them instead of 80 % */
 #define MGL_F_NO_SNAPSHOTS 8u /* do not keep device copies of the all-literal / best base structures:
                               * mgl_sa_begin_epoch then re-derives them from the slab (less memory, slower) */
 

@@ -27,6 +27,7 @@ F_FULLWALK = 2
 F_PROFILE = 4
 F_NO_SNAPSHOTS = 8
 F_SERIAL_BUILD = 16
+F_POSITION_TARGETS = 32
 ACCEPT_AUTO, ACCEPT_SINGLE, ACCEPT_BULK = 0, 1, 2
 
 HIP_SYMBOLS = [

@@ -50,6 +50,10 @@ struct DevCtx {
 	uint32_t max_scan;
 	uint32_t top_k;
 	uint32_t diag_stop;         /* diagnostic: neighbour kernel returns after phase N (0 = run normally) */
+	/* stratified targets (nullptr: MGL_F_POSITION_TARGETS, position draws): packets on the walk before every block of 4 096 positions
+	 * (k_rank_blocks / k_rank_scan, once per step), so that neighbour j can take the packet of a given ordinal */
+	const uint32_t* strat_pre;
+	uint32_t strat_nblk;
 };
 
 struct CkptHdr {
@@ -152,6 +156,37 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
 	}
 	return v;
 }
+/* Stratified target: neighbour j of a step of K takes a packet of the j-th of K equal slices of the
+ * walk's P packets (by ordinal), uniformly inside the slice (draw 0 of its stream).  Every packet is as likely a target as
+ * under independent uniform draws (packet_slab_neighbour.c:162-163 draws an ordinal too), but the K targets of a step are
+ * distinct and spread over the file, so that far fewer improving neighbours of one step overlap.  `pre[b]` = packets that
+ * start before block b of 4 096 positions (k_rank_blocks / k_rank_scan, once per step).  Returns the target position. */
+__device__ __forceinline__ uint32_t stratified_target(const uint64_t* onwalk, uint32_t nw0, const uint32_t* pre, uint32_t nblk,
+                                                      uint32_t P, uint32_t K, uint32_t j, uint32_t u, uint32_t lane)
+{
+	const uint32_t lo_o = (uint32_t)((uint64_t)j * P / K), hi_o = (uint32_t)((uint64_t)(j + 1u) * P / K);
+	uint32_t ord = lo_o + (hi_o > lo_o ? u % (hi_o - lo_o) : 0u);
+	if (ord >= P) ord = P ? P - 1u : 0u;
+	uint32_t lo = 0, hi = nblk; /* pre[lo] <= ord < pre[hi] */
+	while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= ord) lo = mid; else hi = mid; }
+	const uint32_t rem = ord - pre[lo];
+	const uint32_t w = lo * 64u + lane;
+	const uint64_t word = w < nw0 ? onwalk[w] : 0ull;
+	const uint32_t cnt = (uint32_t)__popcll(word);
+	uint32_t incl = cnt;
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t t2 = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)lane >= o) incl += t2; }
+	const unsigned long long has = __ballot(incl > rem);
+	uint32_t tpos = 0;
+	if (has) {
+		const uint32_t l = (uint32_t)__ffsll((long long)has) - 1u;
+		const uint32_t before = rdlane(incl - cnt, l);
+		uint64_t wv = rdlane64(word, l);
+		for (uint32_t q = rem - before; q > 0; q--) wv &= wv - 1ull;
+		tpos = ((lo * 64u + l) << 6) + (uint32_t)__ffsll((long long)wv) - 1u;
+	}
+	return uni(tpos);
+}
+
 /* LDS written by some lanes of this wave is read by others: keep the compiler from moving
  * accesses across (the hardware executes a wave's LDS operations in order). */
 __device__ __forceinline__ void wave_sync()

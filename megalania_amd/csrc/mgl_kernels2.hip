@@ -787,6 +787,14 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		target = uni(crec[2]);
 		nb.pos = uni(crec[3]); nb.ctx_state = uni(crec[4]);
 		nb.dists[0] = uni(crec[5]); nb.dists[1] = uni(crec[6]); nb.dists[2] = uni(crec[7]); nb.dists[3] = uni(crec[8]);
+	} else if (c.strat_pre != nullptr) {
+		target = stratified_target(b.onwalk, b.nw0, c.strat_pre, c.strat_nblk, (uint32_t)ctl->packets, K, j, mgl_rng_draw(rng.key, 0), lane);
+		rng.n = 1;
+		nb = uni_state(base_state_at(b, target));
+		if (MODE == MGL_NBR_PICK && lane == 0) {
+			pickstate[2u * j] = make_uint4(target, rng.n, nb.ctx_state, nb.dists[0]);
+			pickstate[2u * j + 1u] = make_uint4(nb.dists[1], nb.dists[2], nb.dists[3], 0u);
+		}
 	} else {
 		uint32_t mydraw = lane < 32 ? mgl_rng_draw(rng.key, lane) % c.n : 0;
 		bool on = lane < 32 && ((b.onwalk[mydraw >> 6] >> (mydraw & 63u)) & 1ull);
@@ -1393,5 +1401,38 @@ __global__ void __launch_bounds__(64 * MGL_SIM_WAVES_MAX, 8) k_sim(DevCtx c, Bas
 		}
 	} else {
 		sim_one<false, COUNT>(c, b, ctl, out, big, big.sim_hdr, j_base + blockIdx.x, todo, todo_count, sh, traffic_ctr);
+	}
+}
+
+
+/* ================================================================== packets before every block of 4 096 positions (stratified targets) */
+__global__ void __launch_bounds__(64) k_rank_blocks(const uint64_t* onwalk, uint32_t nw0, uint32_t* pre, uint32_t nblk)
+{
+	const uint32_t blk = blockIdx.x, lane = threadIdx.x;
+	if (blk >= nblk) return;
+	const uint32_t w = blk * 64u + lane;
+	unsigned long long v = w < nw0 ? (unsigned long long)__popcll(onwalk[w]) : 0ull;
+	v = wave_sum64(v);
+	if (lane == 0) pre[blk + 1u] = (uint32_t)v;
+}
+__global__ void __launch_bounds__(1024) k_rank_scan(uint32_t* pre, uint32_t nblk)
+{
+	__shared__ uint32_t s_w[16], s_base;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+	if (tid == 0) { s_base = 0; pre[0] = 0; }
+	__syncthreads();
+	for (uint32_t base = 0; base < nblk; base += blockDim.x) {
+		const uint32_t i = base + tid;
+		const uint32_t v = i < nblk ? pre[i + 1u] : 0u;
+		uint32_t incl = v;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)lane >= o) incl += t; }
+		if (lane == 63) s_w[wid] = incl;
+		__syncthreads();
+		uint32_t bsum = s_base;
+		for (uint32_t q = 0; q < wid; q++) bsum += s_w[q];
+		if (i < nblk) pre[i + 1u] = bsum + incl;
+		__syncthreads();
+		if (tid == blockDim.x - 1u) s_base = bsum + incl;
+		__syncthreads();
 	}
 }

@@ -76,10 +76,13 @@ struct orc_ctx {
 	uint32_t* bucket_pos; /* n-1 positions, ascending inside a bucket */
 	uint64_t temperature; /* 0 = the reference's accept rule; else the opt-in Metropolis rule of orc_sa_batched */
 	uint32_t max_bucket_scan; /* 0 = every hit (the reference); else only the nearest M hits of the window */
+	uint32_t strata;          /* batched mode: 0 = the target comes from position draws; K = neighbour j takes a packet of the j-th
+	                           * of K equal slices of the walk's packets (the device's default, mgl_device.h:stratified_target) */
 };
 
 void orc_set_temperature(orc_ctx* c, uint64_t temperature) { c->temperature = temperature; }
 void orc_set_max_bucket_scan(orc_ctx* c, uint32_t m) { c->max_bucket_scan = m; }
+void orc_set_strata(orc_ctx* c, uint32_t K) { c->strata = K; }
 
 size_t orc_num_probs(const orc_ctx* c) { return c->L.total; }
 
@@ -986,14 +989,28 @@ int orc_neighbour_ex(orc_ctx* c, orc_packet* slab, uint64_t seed, uint64_t step,
 	/* target: up to 32 uniform position draws, first one on the walk wins; otherwise the
 	 * next on-walk position at or after the last draw (wrapping to 0) */
 	size_t target = 0;
-	int found = 0;
-	for (int t = 0; t < 32 && !found; t++) {
-		target = ctr_next(&r) % c->n;
-		found = on[target];
-	}
-	if (!found) {
-		while (target < c->n && !on[target]) target++;
-		if (target >= c->n) target = 0;
+	if (c->strata) {
+		/* stratified (the device's default): the packet whose ordinal is drawn uniformly from the j-th of K equal slices of
+		 * the P packets on the walk (packet_slab_neighbour.c:162-163 draws an ordinal from all of them) */
+		const uint32_t K = c->strata;
+		uint64_t P = 0;
+		for (size_t p = 0; p < c->n; p++) P += on[p];
+		const uint64_t lo = (uint64_t)j * P / K, hi = (uint64_t)(j + 1u) * P / K;
+		const uint32_t u = ctr_next(&r);
+		uint64_t ord = lo + (hi > lo ? u % (hi - lo) : 0u);
+		if (ord >= P) ord = P ? P - 1u : 0u;
+		uint64_t k = 0;
+		for (size_t p = 0; p < c->n; p++) if (on[p] && k++ == ord) { target = p; break; }
+	} else {
+		int found = 0;
+		for (int t = 0; t < 32 && !found; t++) {
+			target = ctr_next(&r) % c->n;
+			found = on[target];
+		}
+		if (!found) {
+			while (target < c->n && !on[target]) target++;
+			if (target >= c->n) target = 0;
+		}
 	}
 	free(on);
 	uint64_t total = 0;
@@ -1132,6 +1149,7 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur
 	size_t* nd = (size_t*)malloc(sizeof(size_t) * K);
 	uint8_t* take = (uint8_t*)malloc(K);
 	const uint64_t thresh = ceil_sqrt_u64(iters_per_epoch);
+	if (c->strata) c->strata = K; /* stratified targets: the slices are those of this run's K */
 	for (uint64_t s = step_begin; s < step_end; s++) {
 		const int bulk = modes ? modes[s - step_begin] : 0;
 		if (cur == 0) cur = orc_cost_slab(c, slab, NULL, NULL, NULL, NULL, NULL);

@@ -99,6 +99,9 @@ int orc_sa_batched(orc_ctx* c, orc_packet* slab_io, orc_packet* best_io, uint64_
                    uint64_t* best_cost_io, uint64_t seed, uint32_t K, unsigned phase,
                    uint64_t iters_per_epoch, uint64_t iter0, uint64_t step_begin, uint64_t step_end,
                    const uint8_t* modes, uint64_t* trace, uint64_t* valid_evals, uint64_t* dropped);
+/* batched mode's target rule: K != 0 = stratified by packet ordinal over K neighbours per step (the device's default;
+ * orc_sa_batched takes its own K whenever this is non-zero), 0 = position draws (mgl_sa_config.flags & MGL_F_POSITION_TARGETS) */
+void orc_set_strata(orc_ctx* c, uint32_t K);
 /* cap on the match-index hits a top-K query enumerates (nearest first); mirrors mgl_sa_config.max_bucket_scan */
 void orc_set_max_bucket_scan(orc_ctx* c, uint32_t m);
 

@@ -112,13 +112,17 @@ class Oracle:
             L.orc_neighbour_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
             L.orc_set_max_bucket_scan.argtypes = [C.c_void_p, C.c_uint32]
+            L.orc_set_strata.argtypes = [C.c_void_p, C.c_uint32]
             L.orc_set_temperature.argtypes = [C.c_void_p, C.c_uint64]
             L.orc_emit.restype = C.c_size_t
             L.orc_emit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
             cls._lib = L
         return cls._lib
 
-    def __init__(self, data: bytes, lc=0, lp=0, pb=0, dict_limit=0, max_bucket_scan=0):
+    def __init__(self, data: bytes, lc=0, lp=0, pb=0, dict_limit=0, max_bucket_scan=0, position_targets=False):
+        """position_targets: the batched mode draws targets as positions (mgl_sa_config.flags & MGL_F_POSITION_TARGETS) instead of
+        the device's default, stratified by packet ordinal over the K neighbours of a step (then neighbour() needs K)."""
+        self.stratified = not position_targets
         self.L = self.lib()
         self.data = np.frombuffer(bytes(data), dtype=np.uint8).copy()
         self.n = len(self.data)
@@ -190,7 +194,12 @@ class Oracle:
                                 num_iters, i_begin, i_end, ptr(trace), C.addressof(undo))
         return dict(cur=cur_c.value, best=best_c.value, trace=trace[: 2 * t].reshape(-1, 2).copy(), undo=undo.value)
 
-    def neighbour(self, slab, seed, step, j, keep=False, cap=4096):
+    def _strata(self, K):
+        assert not self.stratified or K, "stratified targets: pass K (the device's neighbours_per_step)"
+        self.L.orc_set_strata(self.h, K if self.stratified else 0)
+
+    def neighbour(self, slab, seed, step, j, keep=False, cap=4096, K=None):
+        self._strata(K)
         cost = C.c_uint64(0)
         nd = C.c_size_t(0)
         diffs = np.zeros(cap, dtype=DIFF)
@@ -199,7 +208,8 @@ class Oracle:
         assert nd.value <= cap
         return bool(ok), cost.value, diffs[: nd.value].copy()
 
-    def neighbour_ex(self, slab, seed, step, j, keep=False, cap=4096):
+    def neighbour_ex(self, slab, seed, step, j, keep=False, cap=4096, K=None):
+        self._strata(K)
         """status (1 ok / 0 no candidate / -1 dropped by the journal capacity), cost, diffs, (target, end, soft end, dep)"""
         cost = C.c_uint64(0)
         nd = C.c_size_t(0)
@@ -221,6 +231,7 @@ class Oracle:
         m = None if modes is None else np.ascontiguousarray(modes, dtype=np.uint8)
         assert m is None or len(m) >= step_end - step_begin
         cur_c, best_c, valid, dropped = C.c_uint64(cur), C.c_uint64(best_cost), C.c_uint64(0), C.c_uint64(0)
+        self._strata(K)
         self.L.orc_sa_batched(self.h, ptr(slab), ptr(best), C.addressof(cur_c), C.addressof(best_c), seed, K, phase,
                               iters_per_epoch, iter0, step_begin, step_end, ptr(m), ptr(trace), C.addressof(valid),
                               C.addressof(dropped))

@@ -95,7 +95,7 @@ def _check_neighbours(sa, o, slab, seed, step, K):
     costs, nd, diffs = sa.neighbours(step)
     bad = []
     for j in range(K):
-        ok, cost, od = o.neighbour(slab, seed, step, j, keep=False)
+        ok, cost, od = o.neighbour(slab, seed, step, j, keep=False, K=K)
         want = cost if ok else binding.INVALID_COST
         if int(costs[j]) != want:
             bad.append((j, int(costs[j]), want))
@@ -239,7 +239,7 @@ def test_windows_and_drop_counter_vs_oracle():
         win2 = sa.debug_dump(22, np.uint32)
         ndrop = 0
         for j in range(K):
-            st, cost, diffs, w = o.neighbour_ex(slab, seed, 777, j)
+            st, cost, diffs, w = o.neighbour_ex(slab, seed, 777, j, K=K)
             ndrop += st == -1
             assert (int(costs[j]) == cost) and (st == 1) == (int(costs[j]) != binding.INVALID_COST), j
             if st == 1:
@@ -286,7 +286,7 @@ def test_full_size_c2_properties():
     base = literal_slab(n)
     costs, nd, diffs = sa.neighbours(0)
     for j in (0, 1, 17, 511, 2048, 4095):
-        ok, cost, od = o.neighbour(base, seed, 0, j, keep=False)
+        ok, cost, od = o.neighbour(base, seed, 0, j, keep=False, K=K)
         assert int(costs[j]) == (cost if ok else binding.INVALID_COST), j
     prev = None
     for _ in range(4):
@@ -317,7 +317,7 @@ def test_pb2_elf_shaped_properties():
     assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]
     costs, nd, diffs = sa.neighbours(2)
     for j in range(0, K, 8):
-        ok, cost, od = o.neighbour(base, seed, 2, j, keep=False)
+        ok, cost, od = o.neighbour(base, seed, 2, j, keep=False, K=K)
         assert int(costs[j]) == (cost if ok else binding.INVALID_COST), j
     sa.run(3)
     cur, cost = sa.current()
@@ -354,7 +354,7 @@ def test_c5_full_size_with_bucket_cap():
     assert cost == o.cost_slab(slab)["total"]
     costs, nd, diffs = sa.neighbours(1000)
     for j in range(0, K, 331):
-        ok, c, od = o.neighbour(slab, seed, 1000, j, keep=False)
+        ok, c, od = o.neighbour(slab, seed, 1000, j, keep=False, K=K)
         assert int(costs[j]) == (c if ok else binding.INVALID_COST), j
     best, _ = sa.best()
     assert lzma.decompress(binding.emit_stream(data, best, pb=2), format=lzma.FORMAT_ALONE) == data
@@ -380,7 +380,7 @@ def test_c4_shape_100_mb():
     assert cost == o.cost_slab(slab)["total"]
     costs, nd, diffs = sa.neighbours(77)
     for j in (5, 9000):
-        ok, c, od = o.neighbour(slab, seed, 77, j, keep=False)
+        ok, c, od = o.neighbour(slab, seed, 77, j, keep=False, K=K)
         assert int(costs[j]) == (c if ok else binding.INVALID_COST), j
         if ok:
             got = [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in diffs[j][: nd[j]]]
@@ -451,7 +451,7 @@ def test_literal_context_and_position_bits(lc, lp, pb):
     assert sa.cost_slab(P(base))["total"] == o.cost_slab(base)["total"]
     costs, nd, diffs = sa.neighbours(1)
     for j in range(0, K, 6):
-        ok, cost, od = o.neighbour(base, seed, 1, j, keep=False)
+        ok, cost, od = o.neighbour(base, seed, 1, j, keep=False, K=K)
         assert int(costs[j]) == (cost if ok else binding.INVALID_COST), j
     sa.run(25)
     cur, cost = sa.current()
@@ -459,7 +459,7 @@ def test_literal_context_and_position_bits(lc, lp, pb):
     costs, nd, diffs = sa.neighbours(77)
     curo = cur.astype(base.dtype)
     for j in range(0, K, 12):
-        ok, c2, od = o.neighbour(curo, seed, 77, j, keep=False)
+        ok, c2, od = o.neighbour(curo, seed, 77, j, keep=False, K=K)
         assert int(costs[j]) == (c2 if ok else binding.INVALID_COST), j
     stream = binding.emit_stream(data, cur, lc=lc, lp=lp, pb=pb)
     assert lzma.decompress(stream, format=lzma.FORMAT_ALONE) == data
@@ -481,7 +481,7 @@ def test_full_size_c3_properties():
     assert sa.current()[1] == o.cost_slab(base)["total"]
     costs, nd, diffs = sa.neighbours(0, want_diffs=False)
     for j in (0, 5, 4097, 16383):
-        ok, cost, od = o.neighbour(base, seed, 0, j, keep=False)
+        ok, cost, od = o.neighbour(base, seed, 0, j, keep=False, K=K)
         assert int(costs[j]) == (cost if ok else binding.INVALID_COST), j
     for s in range(6):
         st = sa.run(1)
@@ -492,7 +492,7 @@ def test_full_size_c3_properties():
     assert sa.cost_slab(P(curo))["total"] == cost          # the one-wavefront full walk agrees
     costs, nd, diffs = sa.neighbours(77, want_diffs=False)
     for j in (3, 9000):
-        ok, c2, od = o.neighbour(curo, seed, 77, j, keep=False)
+        ok, c2, od = o.neighbour(curo, seed, 77, j, keep=False, K=K)
         assert int(costs[j]) == (c2 if ok else binding.INVALID_COST), j
     sa.set_slab(cur)                                         # block-parallel rebuild of the evolved slab
     assert sa.current()[1] == cost
@@ -520,7 +520,7 @@ def test_evolved_c2_neighbours_vs_oracle():
     cf, _, _ = full.neighbours(400, want_diffs=False)
     assert (ca == cf).all()
     for j in range(0, K, 257):
-        ok, c2, od = o.neighbour(curo, seed, 400, j, keep=False)
+        ok, c2, od = o.neighbour(curo, seed, 400, j, keep=False, K=K)
         assert int(ca[j]) == (c2 if ok else binding.INVALID_COST), j
     sa.close()
     full.close()
@@ -686,7 +686,7 @@ def test_full_size_c3_bulk_steps_vs_oracle(monkeypatch):
     assert o.cost_slab(curo)["total"] == cost
     costs, nd, diffs = a.neighbours(steps, want_diffs=True)
     for j in range(0, K, 1024):                      # 16 sampled neighbours of the post-bulk slab
-        ok, c2, od = o.neighbour(curo, seed, steps, j, keep=False)
+        ok, c2, od = o.neighbour(curo, seed, steps, j, keep=False, K=K)
         assert int(costs[j]) == (c2 if ok else binding.INVALID_COST), j
         if ok:
             got = [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in diffs[j][: nd[j]]]

@@ -128,12 +128,12 @@ def test_batched_semantics_selfconsistent():
     assert res["best"] == o.cost_slab(best)["total"] <= res["cur"]
     for j in range(16):
         before = slab.copy()
-        ok, cost, diffs = o.neighbour(slab, 7, 99, j, keep=False)
+        ok, cost, diffs = o.neighbour(slab, 7, 99, j, keep=False, K=16)
         assert (slab == before).all()
         if not ok:
             continue
         kept = slab.copy()
-        ok2, cost2, _ = o.neighbour(kept, 7, 99, j, keep=True)
+        ok2, cost2, _ = o.neighbour(kept, 7, 99, j, keep=True, K=16)
         assert ok2 and cost2 == cost == o.cost_slab(kept)["total"]
         applied = before.copy()
         for d in diffs:

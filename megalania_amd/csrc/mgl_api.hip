@@ -509,6 +509,10 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	if (!split_now || g_big_inline_sim) big_now.sim_hdr2 = nullptr; /* the one-kernel form has no k_sim launch to hand over to */
 	const bool la_step = from_lookahead && split_now;
 	if (la_step) {
+		/* the list-mode instances dereference these unconditionally or behind a test of their partner pointer only (a launch
+		 * of k_neighbours2<true, FULL, true> once faulted on a null address, cause never pinned down: DESIGN.md section 10) */
+		if (!sa->d_la_mark || !sa->d_la_hdr || !sa->d_la_list || !sa->d_todo || !sa->d_todo2 || !sa->d_pickrec || !sa->d_pickstate || !sa->big.ins_key || !sa->big.sim_slot2)
+			return fail(MGL_EDEVICE, "launch_neighbours: look-ahead step without its buffers");
 		/* first the entries the speculative launch made (their count is fixed since k_la_check; the ones evaluated again are passed by) ... */
 		big_now.la_mark = sa->d_la_mark; big_now.la_spec_count = sa->d_la_hdr + 1;
 		big_now.todo_in_count = sa->d_la_hdr + 1;

@@ -14,7 +14,8 @@ marks = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1000
 data, desc = corpus.config_input(cfg)
 n = len(data)
 eng = _libs.Ref(data)
-_libs.Ref.lib().ref_srand(1673551)
+SEED = int(os.environ.get("MGL_CURVE_SEED", "1673551"))  # main.c:68; other seeds: the reference's own spread (tests/golden/reference_spread_c2.json)
+_libs.Ref.lib().ref_srand(SEED)
 slab, best = _libs.literal_slab(n), _libs.literal_slab(n)
 cur = bst = 0
 done, t0, pts = 0, time.perf_counter(), []
@@ -27,5 +28,5 @@ for m in marks:
     stream = len(eng.emit(best))
     pts.append(dict(iterations=done, best_cost=bst, est_bytes=18 + bst / 16384, stream_bytes=stream, seconds=time.perf_counter() - t0))
     print(pts[-1], file=sys.stderr, flush=True)
-out = dict(config=cfg, input=desc, n=n, seed=1673551, phase=0, source="oracle/_ref (compiled from /root/reference/src, glibc rand())", points=pts)
+out = dict(config=cfg, input=desc, n=n, seed=SEED, phase=0, source="oracle/_ref (compiled from /root/reference/src, glibc rand())", points=pts)
 json.dump(out, open(os.environ.get("MGL_CURVE_OUT") or os.path.join(ROOT, "tests", "golden", f"reference_curve_{cfg}.json"), "w"), indent=1)

@@ -140,6 +140,7 @@ struct mgl_sa {
 	BulkBuf bulk;
 	BatchBuf batch;               /* a bulk step that took few moves patches the base instead of rebuilding it (mgl_kernels5.hip) */
 	bool batch_ok = false;
+	uint32_t* d_strat_tgt = nullptr;
 	uint32_t* d_strat_pre = nullptr; /* stratified targets: packets before every block of 4 096 positions */
 	bool select_small = false;    /* the previous bulk step had few acceptable neighbours: this one's selection runs as one launch */
 	uint64_t batch_accepts = 0, batch_fallbacks = 0; /* bulk steps whose moves were patched in / that went to the rebuild although a batch accept began */
@@ -431,6 +432,7 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 		const uint32_t nw0 = sa->incremental ? sa->b2.nw0 : (sa->ctx.n + 63u) >> 6;
 		hipLaunchKernelGGL(k_rank_blocks, dim3(sa->ctx.strat_nblk), dim3(64), 0, sa->stream, onwalk, nw0, sa->d_strat_pre, sa->ctx.strat_nblk);
 		hipLaunchKernelGGL(k_rank_scan, dim3(1), dim3(1024), 0, sa->stream, sa->d_strat_pre, sa->ctx.strat_nblk);
+		hipLaunchKernelGGL(k_targets, dim3((K + 3u) / 4u), dim3(256), 0, sa->stream, sa->ctx, onwalk, nw0, (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->d_strat_tgt);
 	}
 	if (!sa->incremental) {
 		const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
@@ -616,7 +618,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
-	dfree(sa->big.cont); dfree(sa->d_traffic); dfree(sa->d_strat_pre);
+	dfree(sa->big.cont); dfree(sa->d_traffic); dfree(sa->d_strat_pre); dfree(sa->d_strat_tgt);
 	{
 		BatchBuf& bt = sa->batch;
 		dfree(bt.hdr); dfree(bt.cl); dfree(bt.jpos); dfree(bt.jnew); dfree(bt.jold); dfree(bt.st_ikey); dfree(bt.st_rkey); dfree(bt.st_ipos);
@@ -1086,11 +1088,13 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 
 	/* targets: stratified by packet ordinal (default), or position draws (MGL_F_POSITION_TARGETS; the look-ahead needs them:
 	 * it keeps speculative results whose target draw lands on the same position after the accept) */
-	if (!(sa->cfg.flags & MGL_F_POSITION_TARGETS) && !sa->la_enabled) {
+	if (!(sa->cfg.flags & MGL_F_POSITION_TARGETS) && !sa->la_enabled && getenv("MGL_POSITION_TARGETS") == nullptr) { /* (the environment switch: A/B runs) */
 		sa->ctx.strat_nblk = (uint32_t)((n + 4095u) / 4096u);
 		HIPCHK(hipMalloc(&sa->d_strat_pre, sizeof(uint32_t) * (sa->ctx.strat_nblk + 2u)));
 		HIPCHK(hipMemset(sa->d_strat_pre, 0, sizeof(uint32_t) * (sa->ctx.strat_nblk + 2u)));
 		sa->ctx.strat_pre = sa->d_strat_pre;
+		HIPCHK(hipMalloc(&sa->d_strat_tgt, sizeof(uint32_t) * sa->cfg.neighbours_per_step));
+		sa->ctx.strat_tgt = sa->d_strat_tgt;
 	}
 	sa->sqrt_thresh = ceil_sqrt_u64(sa->cfg.iters_per_epoch);
 	/* a bulk step costs a parallel rebuild (about 3 single steps at 100 KB, 6 at 10 MB, 20 at 100 MB) */

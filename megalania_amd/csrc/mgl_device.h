@@ -54,6 +54,7 @@ struct DevCtx {
 	 * (k_rank_blocks / k_rank_scan, once per step), so that neighbour j can take the packet of a given ordinal */
 	const uint32_t* strat_pre;
 	uint32_t strat_nblk;
+	const uint32_t* strat_tgt;  /* K: the step's targets, made from strat_pre by k_targets before the neighbour kernels run */
 };
 
 struct CkptHdr {

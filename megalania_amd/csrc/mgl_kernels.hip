@@ -886,7 +886,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 	 * (the reference draws a packet ordinal, packet_slab_neighbour.c:162-163) */
 	uint32_t target;
 	if (c.strat_pre != nullptr) {
-		target = stratified_target(b.onwalk, (c.n + 63u) >> 6, c.strat_pre, c.strat_nblk, (uint32_t)ctl->packets, K, j, mgl_rng_draw(rng.key, 0), lane);
+		target = uni(c.strat_tgt[j]); /* stratified_target(), worked out for the whole step by k_targets */
 		rng.n = 1;
 	} else {
 		uint32_t mydraw = lane < 32 ? mgl_rng_draw(rng.key, lane) % c.n : 0;

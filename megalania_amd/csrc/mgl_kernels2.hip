@@ -788,7 +788,7 @@ __device__ __forceinline__ void nbr2_one(const DevCtx& c, const Base2& b, Contro
 		nb.pos = uni(crec[3]); nb.ctx_state = uni(crec[4]);
 		nb.dists[0] = uni(crec[5]); nb.dists[1] = uni(crec[6]); nb.dists[2] = uni(crec[7]); nb.dists[3] = uni(crec[8]);
 	} else if (c.strat_pre != nullptr) {
-		target = stratified_target(b.onwalk, b.nw0, c.strat_pre, c.strat_nblk, (uint32_t)ctl->packets, K, j, mgl_rng_draw(rng.key, 0), lane);
+		target = uni(c.strat_tgt[j]); /* stratified_target(), worked out for the whole step by k_targets */
 		rng.n = 1;
 		nb = uni_state(base_state_at(b, target));
 		if (MODE == MGL_NBR_PICK && lane == 0) {
@@ -1435,4 +1435,17 @@ __global__ void __launch_bounds__(1024) k_rank_scan(uint32_t* pre, uint32_t nblk
 		if (tid == blockDim.x - 1u) s_base = bsum + incl;
 		__syncthreads();
 	}
+}
+
+/* the step's targets: one wavefront per neighbour (mgl_device.h:stratified_target; draw 0 of the neighbour's stream picks the
+ * packet inside its slice).  A kernel of its own: in the pick kernel, sixteen wavefronts per CU, the same search was a
+ * dozen dependent loads at the head of every wavefront's critical path */
+__global__ void __launch_bounds__(256) k_targets(DevCtx c, const uint64_t* onwalk, uint32_t nw0, const Control* ctl, uint64_t seed, uint64_t step_override,
+                                                 uint32_t K, uint32_t* tgt)
+{
+	const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (j >= K) return;
+	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
+	const uint32_t t = stratified_target(onwalk, nw0, c.strat_pre, c.strat_nblk, (uint32_t)ctl->packets, K, j, mgl_rng_draw(mgl_rng_key(seed, gstep, j), 0), lane);
+	if (lane == 0) tgt[j] = t;
 }

@@ -38,8 +38,10 @@ trace.sort(key=lambda r: int(r["Dispatch_Id"]))
 names = [short(r["Kernel_Name"]) for r in trace]
 # the last step ends with k_build_end (single step); walk back `steps` of them
 ends = [i for i, n in enumerate(names) if n == "k_build_end"]
+if len(ends) < 3:
+    raise SystemExit(f"only {len(ends)} single steps in the trace")
 if len(ends) <= steps:
-    raise SystemExit(f"only {len(ends)} single steps in the trace, need more than {steps}")
+    steps = len(ends) - 1  # (the set-up phase may consist of bulk steps only: average over the single steps there are)
 first = ends[-steps - 1] + 1
 tail = trace[first:]
 per_step = collections.Counter(short(r["Kernel_Name"]) for r in tail)

@@ -27,6 +27,8 @@ while prepare != 0 and done < (prepare if prepare > 0 else PREPARE_CAP[cfg]):
         break
 if os.environ.get("MGL_RUN_ACCEPT"):  # the accept mode of the measured steps (default: the library's, auto)
     sa.set_accept_mode(os.environ["MGL_RUN_ACCEPT"])
+if os.environ.get("MGL_RUN_WARM"):
+    sa.run(int(os.environ["MGL_RUN_WARM"]))
 st = sa.run(steps)
 print("batch accepts / fallbacks", sa.batch_counters())
 print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()})

@@ -254,7 +254,9 @@ int mgl_neighbours(mgl_sa* sa, uint64_t global_step, uint64_t* costs, mgl_diff* 
  * serially (exercises its fallback); key 2 = shrink the first-pass change lists (a multiple of 8,
  * at most the allocated size) so that neighbours overflow into the second pass (exercises it); key 3 = treat the
  * next so many bulk steps that took moves as failed validations (exercises the rollback); key 4 = 1 / 0: the
- * re-simulation kernel adds up the bytes it reads (mgl_sa_stats.sim_bytes_counted; a few percent slower). */
+ * re-simulation kernel adds up the bytes it reads (mgl_sa_stats.sim_bytes_counted; a few percent slower); key 5 = n: the next
+ * n batch accepts (bulk steps that patch few moves into the base structures) give up after they have written their journals
+ * and bitmaps (exercises the fallback to the rebuild from there). */
 int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_bytes, size_t* bytes);
 int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value);
 /* draw n of neighbour j at global step `step` (31-bit, like rand()); j = 0xFFFFFFFF is the

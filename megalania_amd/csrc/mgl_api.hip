@@ -143,6 +143,7 @@ struct mgl_sa {
 	uint32_t* d_strat_tgt = nullptr;
 	uint32_t* d_strat_pre = nullptr; /* stratified targets: packets before every block of 4 096 positions */
 	bool select_small = false;    /* the previous bulk step had few acceptable neighbours: this one's selection runs as one launch */
+	uint32_t force_batch_fail = 0; /* diagnostic (mgl_debug_set key 5): the next so many batch accepts give up behind their commit */
 	uint64_t batch_accepts = 0, batch_fallbacks = 0; /* bulk steps whose moves were patched in / that went to the rebuild although a batch accept began */
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
 	uint32_t force_rollbacks = 0;  /* diagnostic: treat the next so many bulk steps that took moves as failed validations */
@@ -1347,8 +1348,9 @@ static int launch_bulk_tail(mgl_sa* sa)
 	/* A step that took few moves patches the base structures for all of them at once (mgl_kernels5.hip); every kernel of
 	 * that looks at the status word first, so a step that took none, or too many, passes through in a few microseconds. */
 	uint32_t bstat[8] = { 2u, 0, 0, 0, 0, 0, 0, 0 }; /* without the batch path: everything is the rebuild's */
-	if (sa->batch_ok) {
+	if (sa->batch_ok && !sa->force_rollbacks) { /* (the rollback net hangs under the rebuild: while a test forces it, steps go that way) */
 		Base2& b = sa->b2;
+		if (sa->force_batch_fail) { const uint32_t one = 1u; HIPCHK(hipMemcpyAsync(sa->batch.hdr + 9, &one, sizeof one, hipMemcpyHostToDevice, sa->stream)); }
 		hipLaunchKernelGGL(k_batch_clusters, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->batch);
 		hipLaunchKernelGGL(k_batch_walk, dim3(MGL_BATCH_MAX), dim3(64), 0, sa->stream, sa->ctx, b, sa->batch);
 		hipLaunchKernelGGL(k_batch_commit, dim3(MGL_BATCH_MAX), dim3(256), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
@@ -1364,6 +1366,11 @@ static int launch_bulk_tail(mgl_sa* sa)
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(bstat, sa->batch.hdr, sizeof bstat, hipMemcpyDeviceToHost, sa->stream));
 		HIPCHK(hipStreamSynchronize(sa->stream));
+		if (sa->force_batch_fail) {
+			const uint32_t zero = 0u;
+			HIPCHK(hipMemcpy(sa->batch.hdr + 9, &zero, sizeof zero, hipMemcpyHostToDevice));
+			if (bstat[0] == 1u) sa->force_batch_fail--; /* (a step that took nothing, or went to the rebuild anyway, does not count) */
+		}
 	}
 	if (sa->batch_ok) sa->select_small = bstat[7] <= 512u; /* this step's acceptable neighbours size the next step's selection */
 	if (bstat[0] == 3u) sa->batch_accepts++; /* the moves are in: structures patched, exact cost in Control::rebuild_cost, every rep packet of the new walk checked */
@@ -1789,6 +1796,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 /* diagnostic knobs (tools/, tests/): key 0 = stop the neighbour kernel after phase `value`; key 1 = see below */
 extern "C" int mgl_debug_set(mgl_sa* sa, uint32_t key, uint64_t value)
 {
+	if (sa && key == 5) { sa->force_batch_fail = (uint32_t)value; return MGL_OK; } /* the next `value` batch accepts give up behind their commit (exercises the fallback to the rebuild) */
 	if (sa && key == 4) { /* count the bytes of chain data the re-simulation kernel reads (mgl_sa_stats.sim_bytes_counted) */
 		if (!sa->d_traffic) return fail(MGL_EINVAL, "mgl_debug_set: no split neighbour evaluation on this handle");
 		sa->count_traffic = value != 0;

@@ -36,7 +36,7 @@
  */
 #include "mgl_base2.h"
 
-#define MGL_BATCH_MAX 64u      /* taken neighbours a batch accept handles */
+#define MGL_BATCH_MAX 128u     /* taken neighbours a batch accept handles */
 #define MGL_BATCH_JCAP 512u    /* journal entries per cluster */
 #define MGL_BATCH_EVCAP 4096u  /* inserted / removed events staged per cluster */
 #define MGL_BATCH_OPCAP 2048u  /* bitmap / state-record ops per cluster */
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256) k_batch_fill(BatchBuf bt, ApplyBuf ab)
 }
 
 /* ------------------------------------------------------------------ chains */
-#define MGL_BATCH_THREADS 64u /* one wavefront per touched context; a thread per group (<= MGL_BATCH_MAX) */
+#define MGL_BATCH_THREADS MGL_BATCH_MAX /* one workgroup per touched context; a thread per group */
 
 struct RunOut {
 	uint32_t k_start, k_end; /* old entries [k_start, k_end) are replaced */
@@ -587,7 +587,8 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 	__shared__ int32_t s_hdelta[MGL_BATCH_MAX + 1]; /* length change accumulated up to and including head h */
 	__shared__ uint32_t s_ng, s_nh, s_fail, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
 	if (bt.hdr[0] != 1u || bt.hdr[4]) return;
-	/* one workgroup (one wavefront) per context: most have nothing to do */
+	if (bt.hdr[9]) { if (blockIdx.x == 0 && threadIdx.x == 0) ctl->apply_failed = 1; return; } /* test hook (mgl_debug_set key 5): give up behind the commit */
+	/* one workgroup per context: most have nothing to do */
 	const uint32_t cx = blockIdx.x;
 	if (cx >= bt.nctx) return;
 	const uint32_t ni = bt.cnt_i[cx], nr = bt.cnt_r[cx];

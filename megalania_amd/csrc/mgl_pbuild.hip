@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(64) pb_sim_fix(DevCtx c, Base2 b, PBuild pb)
  * sentinel holds the final value).  Lane = context; rows leave through LDS as 128-byte stores. */
 __global__ void __launch_bounds__(64) pb_ckpt(DevCtx c, Base2 b)
 {
-	__shared__ uint16_t tile[MGL_PB_CK_ROWS * 64];
+	__shared__ __attribute__((aligned(16))) uint16_t tile[MGL_PB_CK_ROWS * 64];
 	if (*b.pool_top > b.pool_cap) return;
 	const uint32_t lane = threadIdx.x, ctx = blockIdx.x * 64 + lane;
 	const uint32_t k0 = blockIdx.y * MGL_PB_CK_ROWS, k1 = (k0 + MGL_PB_CK_ROWS) < b.nck ? (k0 + MGL_PB_CK_ROWS) : b.nck;
@@ -714,8 +714,12 @@ __global__ void __launch_bounds__(64) pb_ckpt(DevCtx c, Base2 b)
 		for (uint32_t k = k0; k < k1; k++) tile[(k - k0) * 64 + lane] = MGL_PROB_INIT;
 	}
 	__syncthreads();
-	if (ctx < b.ck_elems)
-		for (uint32_t k = k0; k < k1; k++) b.ck_probs[(size_t)k * b.ck_elems + ctx] = tile[(k - k0) * 64 + lane];
+	/* rows leave as 16-byte stores: eight lanes cover a row's 64 contexts, a store instruction eight rows (rows are 16-byte
+	 * multiples; 128 bytes per instruction -- one row, two bytes a lane -- took 64 instructions per tile) */
+	const uint32_t seg = lane & 7u, c0 = blockIdx.x * 64u + seg * 8u;
+	if (c0 < b.ck_elems)
+		for (uint32_t k = k0 + (lane >> 3); k < k1; k += 8u)
+			*reinterpret_cast<uint4*>(b.ck_probs + (size_t)k * b.ck_elems + c0) = *reinterpret_cast<const uint4*>(tile + (k - k0) * 64u + seg * 8u);
 }
 
 __global__ void pb_finish(PBuild pb, Control* ctl)

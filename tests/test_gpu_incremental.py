@@ -222,6 +222,53 @@ def test_batch_accept_equals_rebuild(name, K, steps, golden, golden_input, monke
     inc.close(); full.close(); ref.close()
 
 
+def test_batch_accept_that_gives_up_falls_back_to_the_rebuild(monkeypatch):
+    """The batch accept's own fallback -- it has written journals and bitmaps, then a capacity is exceeded while the chains are
+    rewritten -- has never been taken by a real step; mgl_debug_set key 5 forces it.  The step must end exactly where the
+    chain without the batch path ends (rebuild from the slab the commit left), and the next steps go on patching in place."""
+    data = corpus.enwik_like(30000, 0x5151)
+    a = binding.SA(data, accept="bulk", neighbours_per_step=256, seed=9, iters_per_epoch=10**7)
+    monkeypatch.setenv("MGL_NO_BATCH", "1")
+    b = binding.SA(data, accept="bulk", neighbours_per_step=256, seed=9, iters_per_epoch=10**7)
+    monkeypatch.delenv("MGL_NO_BATCH")
+    ref = binding.SA(data, accept="single", neighbours_per_step=8, seed=5)
+    for x in (a, b):
+        x.run(12)
+    a.debug_set(5, 3)
+    for s in range(8):
+        sa_, sb_ = a.run(1), b.run(1)
+        assert sa_["current_cost"] == sb_["current_cost"] and sa_["accepted"] == sb_["accepted"] and sa_["bulk_rollbacks"] == 0, s
+        cur, cost = a.current()
+        assert (cur == b.current()[0]).all()
+        ref.set_slab(cur)
+        assert_same_base(canonical_base(a, cur), canonical_base(ref, cur), ("forced", s))
+    acc, fb = a.batch_counters()
+    assert fb == 3 and acc >= 12 + 8 - 3 - 4   # three forced fallbacks; the other steps (but the first few, whose windows do not close) patched in place
+    a.close(); b.close(); ref.close()
+
+
+def test_full_size_c2_batch_path_vs_rebuild_path(monkeypatch):
+    """BASELINE configs[1] at full size, 160 bulk steps (what the default accept mode runs there; the mode is pinned because AUTO's
+    switch-over rule knows what a bulk step costs and so differs between the two chains): the chain whose bulk steps patch
+    their moves in (at most MGL_BATCH_MAX of them, else rebuild) against the chain that always rebuilds -- same costs step
+    by step, same slab, cost == the oracle's walk, stream round-trips."""
+    data, _ = corpus.config_input("c2")
+    a = binding.SA(data, neighbours_per_step=4096, seed=1673551, iters_per_epoch=len(data), accept="bulk")
+    monkeypatch.setenv("MGL_NO_BATCH", "1")
+    b = binding.SA(data, neighbours_per_step=4096, seed=1673551, iters_per_epoch=len(data), accept="bulk")
+    monkeypatch.delenv("MGL_NO_BATCH")
+    for s in range(16):
+        sa_, sb_ = a.run(10), b.run(10)
+        for k in ("current_cost", "best_cost", "accepted", "evaluations", "bulk_steps"):
+            assert sa_[k] == sb_[k], (s, k)
+    cur, cost = a.current()
+    assert (cur == b.current()[0]).all()
+    assert cost == Oracle(data, dict_limit=0x400000).cost_slab(cur.astype(literal_slab(1).dtype))["total"]
+    assert a.batch_counters()[0] > 40 and a.batch_counters()[1] == 0
+    assert lzma.decompress(binding.emit_stream(data, a.best()[0]), format=lzma.FORMAT_ALONE) == data
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("name,K", [("lorem4k", 64), ("enwik3k", 96)])
 def test_epoch_snapshots_equal_rebuild(name, K, golden, golden_input):
     """mgl_sa_begin_epoch restores the all-literal / best base structures from device copies;

@@ -217,7 +217,9 @@ static int alloc_b2(Base2& b, size_t n, bool own_slab, bool init, size_t* bytes_
 	HIPCHK(hipMalloc(&b.ch_pos, sizeof(uint32_t) * b2_pool_entries(b))); bytes += sizeof(uint32_t) * (size_t)b.pool_cap;
 	HIPCHK(hipMalloc(&b.ch_ev, sizeof(uint16_t) * b2_pool_entries(b))); bytes += sizeof(uint16_t) * (size_t)b.pool_cap;
 	HIPCHK(hipMalloc(&b.pool_top, sizeof(uint32_t)));
+	HIPCHK(hipMalloc(&b.ch_sb, sizeof(uint32_t) * (size_t)b.ck_elems * b.sb_stride)); bytes += sizeof(uint32_t) * (size_t)b.ck_elems * b.sb_stride;
 	if (init) {
+		HIPCHK(hipMemset(b.ch_sb, 0, sizeof(uint32_t) * (size_t)b.ck_elems * b.sb_stride));
 		HIPCHK(hipMemset(b.sp0, 0, sizeof(uint64_t) * (b.nw0 + 64)));
 		HIPCHK(hipMemset(b.sp1, 0, sizeof(uint64_t) * (b.nw1 + 64)));
 		HIPCHK(hipMemset(b.sp2, 0, sizeof(uint64_t) * (b.nw2 + 64)));
@@ -231,7 +233,7 @@ static void free_b2(Base2& b, bool own_slab)
 {
 	if (own_slab) { dfree(b.slab); dfree(b.onwalk); }
 	dfree(b.sp0); dfree(b.sp1); dfree(b.sp2); dfree(b.sp_state); dfree(b.ck_probs);
-	dfree(b.ch_off); dfree(b.ch_len); dfree(b.ch_cap); dfree(b.ch_pos); dfree(b.ch_ev); dfree(b.pool_top);
+	dfree(b.ch_off); dfree(b.ch_len); dfree(b.ch_cap); dfree(b.ch_pos); dfree(b.ch_ev); dfree(b.pool_top); dfree(b.ch_sb);
 	memset(&b, 0, sizeof b);
 }
 /* dir 0: base -> snapshot, dir 1: snapshot -> base; cond: only if this step found a new best */
@@ -259,6 +261,7 @@ static int launch_snapshot(mgl_sa* sa, Base2& snap, uint32_t which, int dir, int
 	seg(from.ch_pos, to.ch_pos, sizeof(uint32_t) * b2_pool_entries(from), 4);
 	seg(from.ch_ev, to.ch_ev, sizeof(uint16_t) * b2_pool_entries(from), 2);
 	seg(from.pool_top, to.pool_top, sizeof(uint32_t), 0);
+	seg(from.ch_sb, to.ch_sb, sizeof(uint32_t) * (size_t)from.ck_elems * from.sb_stride, 0);
 	p.nseg = k;
 	p.src_pool_top = from.pool_top;
 	hipLaunchKernelGGL(k_snapshot, dim3(2048), dim3(256), 0, sa->stream, p, sa->base.ctl, sa->d_snap_meta + which, dir, cond);
@@ -309,6 +312,7 @@ static int launch_pbuild(mgl_sa* sa, bool validate_beside = false)
 		hipLaunchKernelGGL(pb_offsets_sum, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb);
 		hipLaunchKernelGGL(pb_offsets_top, dim3((b.ck_elems + 255) / 256), dim3(256), 0, st, b, pb, total, og);
 		hipLaunchKernelGGL(pb_offsets, dim3((b.ck_elems + 255) / 256, og), dim3(256), 0, st, b, pb, total);
+		hipLaunchKernelGGL(pb_index, dim3((total + 31u) / 32u, (pb.nblk + 1u + 31u) / 32u), dim3(256), 0, st, b, pb, total);
 	}
 	hipLaunchKernelGGL(pb_layout, dim3(1), dim3(64), 0, st, b, pb, ctl, total);
 	hipLaunchKernelGGL(pb_scatter, dim3(pb.nblk), dim3(256), b.ck_elems * 4u, st, b, pb, total);
@@ -831,6 +835,10 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		b.nck = (uint32_t)(((size_t)n + (1u << MGL_CK2_SHIFT) - 1) >> MGL_CK2_SHIFT);
 		b.ck_elems = ckpt_elems;
 		b.pool_cap = (uint32_t)(24 * n + (size_t)L.total * 272 + 4096);
+		/* chain index: one entry per context and block of the parallel builder (the builder's per-block counts are its source) */
+		b.sb_shift = n <= (1u << 20) ? 8u : n <= (1u << 23) ? 9u : MGL_PB_MAX_SHIFT;
+		b.nsb = (uint32_t)((n + (1u << b.sb_shift) - 1) >> b.sb_shift);
+		b.sb_stride = (b.nsb + 2u + 3u) & ~3u;
 		size_t bytes = 0;
 		{
 			int rc = alloc_b2(b, n, false, true, &bytes);
@@ -840,7 +848,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 		if (sa->parallel_build) {
 			PBuild& pb = sa->pb;
 			memset(&pb, 0, sizeof pb);
-			pb.shift = n <= (1u << 20) ? 8u : n <= (1u << 23) ? 9u : MGL_PB_MAX_SHIFT;
+			pb.shift = b.sb_shift; /* 256 / 512 / 1 024 positions per block up to 1 MiB / 8 MiB / above */
 			pb.nblk = (uint32_t)((n + (1u << pb.shift) - 1) >> pb.shift);
 			HIPCHK(hipMalloc(&pb.exits, sizeof(uint16_t) * (size_t)pb.nblk * MGL_PB_ENTRIES));
 			HIPCHK(hipMalloc(&pb.entry, sizeof(uint32_t) * ((size_t)pb.nblk + 1)));
@@ -1760,6 +1768,7 @@ extern "C" int mgl_debug_dump(mgl_sa* sa, uint32_t what, void* out, size_t cap_b
 		if (cap_bytes >= sizeof v) memcpy(out, v, sizeof v);
 		return MGL_OK;
 	}
+	case 83: src = b.ch_sb; sz = sizeof(uint32_t) * (size_t)b.ck_elems * b.sb_stride; break; /* the chain index, row per context, sb_stride words each */
 	case 81: src = sa->batch.hdr; sz = sizeof(uint32_t) * 16; break;
 	case 82: src = sa->batch.acc; sz = sizeof(long long) * 4; break;
 	case 10: src = sa->d_counts + 8; sz = sizeof(uint32_t) * 4; break; /* of the last finished step / mgl_neighbours call */

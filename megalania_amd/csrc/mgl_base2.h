@@ -55,6 +55,11 @@ struct Base2 {
 	uint16_t* ch_ev;      /* bit << 15 | probability before the update */
 	uint32_t pool_cap;
 	uint32_t* pool_top;
+	/* chain index (round 3): ch_sb[c * sb_stride + b] = entries of context c's chain with a position below b << sb_shift
+	 * (b = 0 .. nsb; the last one is the chain's length): a search for a position starts inside one block's entries instead
+	 * of over the whole chain -- two index loads and one or two probes instead of nine dependent round trips */
+	uint32_t* ch_sb;
+	uint32_t sb_shift, nsb, sb_stride;
 };
 
 __device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t)__ffsll((long long)v) - 1u; }
@@ -147,6 +152,15 @@ __device__ __forceinline__ mgl_wstate uni_state(mgl_wstate s)
 	return s;
 }
 
+/* the stretch of context c's chain that holds position x: entries before *lo are below x's block, entry *hi is behind it */
+__device__ __forceinline__ void chain_block(const Base2& b, uint32_t c, uint32_t x, uint32_t* lo, uint32_t* hi)
+{
+	const uint32_t* row = b.ch_sb + (size_t)c * b.sb_stride;
+	uint32_t blk = x >> b.sb_shift;
+	if (blk >= b.nsb) blk = b.nsb - 1u;
+	const uint2 v = make_uint2(row[blk], row[blk + 1u]);
+	*lo = v.x; *hi = v.y;
+}
 /* first chain entry of context c whose packet position is >= x (the sentinel if none) */
 #ifndef MGL_LB_WIDE_ABOVE
 #define MGL_LB_WIDE_ABOVE 32768u

@@ -143,13 +143,17 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 	for (uint32_t i = lane; i < b.ck_elems; i += 64) { cnt[i] = 0; probs[i] = MGL_PROB_INIT; }
 	wave_sync();
 
-	/* ---- pass 2: chains + dense checkpoints + cost */
+	/* ---- pass 2: chains + dense checkpoints + chain index + cost */
 	walk_reset(w);
-	uint32_t next_ck = 0;
+	uint32_t next_ck = 0, next_sb = 0;
 	guard = 0;
 	while (w.st.pos < c.n) {
 		const uint32_t pos = w.st.pos;
 		if (++guard > c.n) break;
+		while (next_sb <= (pos >> b.sb_shift)) { /* entries per context before this block */
+			for (uint32_t i = lane; i < total; i += 64) b.ch_sb[(size_t)i * b.sb_stride + next_sb] = cnt[i];
+			next_sb++;
+		}
 		while (next_ck < b.nck && (next_ck << MGL_CK2_SHIFT) <= pos) {
 			uint32_t* dst = (uint32_t*)(b.ck_probs + (size_t)next_ck * b.ck_elems);
 			const uint32_t* src = (const uint32_t*)probs;
@@ -191,6 +195,8 @@ __device__ void build_body(const DevCtx& c, const Base2& b, Control* ctl, int ch
 		for (uint32_t i = lane; i < b.ck_elems / 2; i += 64) dst[i] = src[i];
 		next_ck++;
 	}
+	for (; next_sb <= b.nsb; next_sb++)
+		for (uint32_t i = lane; i < total; i += 64) b.ch_sb[(size_t)i * b.sb_stride + next_sb] = cnt[i];
 	/* sentinels: position = infinity, probability = the context's final value */
 	for (uint32_t i = lane; i < total; i += 64) {
 		const uint32_t k = off[i] + cnt[i];
@@ -356,8 +362,10 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 		const uint16_t* cev = b.ch_ev + b.ch_off[cx];
 		const uint32_t clen = b.ch_len[cx];
 		uint32_t probes = 0;
-		uint32_t k = chain_lower_bound(cpos, clen, x0, traffic ? &probes : nullptr);
-		if (traffic) *traffic += 12u; /* chain offset and length of this context */
+		uint32_t blo, bhi; /* the chain index narrows the search to the entries of x0's block */
+		chain_block(b, cx, x0, &blo, &bhi);
+		uint32_t k = chain_lower_bound(cpos, bhi, x0, traffic ? &probes : nullptr, blo);
+		if (traffic) *traffic += 20u; /* chain offset and length of this context, two index entries */
 		/* eight chain entries (positions + events) per round trip, kept in registers */
 		uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa, c_ev = c_pa;
 		uint32_t c_base = 0xFFFFFFFFu;
@@ -414,7 +422,9 @@ __device__ __forceinline__ int64_t chain_sim_contexts(const Base2& b, Changes& c
 				const uint32_t nxt = ipos < rpos ? ipos : rpos;
 				if (nxt > bpos) {
 					if (nxt >= limit) { ended = true; break; } /* the base value holds at the limit */
-					k = chain_lower_bound(cpos, clen, nxt, traffic ? &probes : nullptr, k);
+					chain_block(b, cx, nxt, &blo, &bhi);
+					k = chain_lower_bound(cpos, bhi, nxt, traffic ? &probes : nullptr, blo > k ? blo : k);
+					if (traffic) *traffic += 8u;
 					chunk(k);
 					p = ev_at(k) & 0x7FFu;
 					continue;

@@ -375,6 +375,22 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
 		uint32_t* cpos = b.ch_pos + off;
 		uint16_t* cev = b.ch_ev + off;
+		/* ---- 1b. the chain index: every block behind the first change has (inserted - removed events below it) more entries
+		 * before it (the lists are in position order) */
+		{
+			const uint32_t ni = s_ni, nr = s_nr;
+			const uint32_t first = ((ni ? s_ipos[0] : MGL_POS_INF) < (nr ? s_rpos[0] : MGL_POS_INF)) ? s_ipos[0] : s_rpos[0];
+			uint32_t* row = b.ch_sb + (size_t)cx * b.sb_stride;
+			for (uint32_t blk = (first >> b.sb_shift) + 1u + tid; blk <= b.nsb; blk += MGL_APPLY_THREADS) {
+				const uint32_t bound = blk == b.nsb ? MGL_POS_INF : blk << b.sb_shift;
+				uint32_t a = 0, z = ni;
+				while (a < z) { const uint32_t m = (a + z) >> 1; if (s_ipos[m] < bound) a = m + 1; else z = m; }
+				const uint32_t di = a;
+				a = 0; z = nr;
+				while (a < z) { const uint32_t m = (a + z) >> 1; if (s_rpos[m] < bound) a = m + 1; else z = m; }
+				if (di != a) row[blk] += di - a;
+			}
+		}
 		/* ---- 2. re-simulate: new entries, pieces, checkpoint segments.  First the whole workgroup
 		 * finds the chain entry of the first change (1024-ary search) and stages the entries from
 		 * there on in LDS; then one thread walks them. */

@@ -462,12 +462,21 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
                                             const uint32_t* s_ipos, const uint16_t* s_ibit, const uint8_t* s_icl, uint32_t ni,
                                             const uint32_t* s_rpos, const uint8_t* s_rcl, uint32_t nr,
                                             uint32_t ii, uint32_t ri, const uint8_t* s_gcl, uint32_t g,
-                                            uint32_t* span_pos, uint16_t* span_ev, uint32_t at, uint32_t wcap)
+                                            uint32_t* span_pos, uint16_t* span_ev, uint32_t at, uint32_t wcap,
+                                            const uint32_t* sb_row, uint32_t sb_row_info /* nsb | sb_shift << 24 */)
 {
 	RunOut r; /* (WRITE: only the first `wcap` new entries are written; the sizes are exact whatever it is) */
 	uint32_t ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF, rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
 	const uint32_t x0 = ipos < rpos ? ipos : rpos;
-	uint32_t k = chain_lower_bound(cpos, len, x0);
+	uint32_t k;
+	{
+		uint32_t blo, bhi; /* the chain index (still the old chain's: patched at the end of the kernel) narrows the search */
+		const uint32_t nsb = sb_row_info & 0xFFFFFFu, shift = sb_row_info >> 24;
+		uint32_t blk = x0 >> shift;
+		if (blk >= nsb) blk = nsb - 1u;
+		blo = sb_row[blk]; bhi = sb_row[blk + 1u];
+		k = chain_lower_bound(cpos, bhi, x0, nullptr, blo);
+	}
 	r.k_start = k; r.lo = x0; r.uncoupled = 0; r.hi = MGL_POS_INF;
 	/* eight chain entries (positions + events) per round trip, kept in registers (as in chain_sim_contexts: chains start
 	 * 32-byte aligned, the pool is over-allocated past its end) */
@@ -638,6 +647,11 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		const uint32_t off = b.ch_off[cx], len = b.ch_len[cx], cap = b.ch_cap[cx];
 		const uint32_t* cpos = b.ch_pos + off;
 		const uint16_t* cev = b.ch_ev + off;
+		uint32_t* const sb_row = b.ch_sb + (size_t)cx * b.sb_stride;
+		const uint32_t sb_info = b.nsb | (b.sb_shift << 24);
+		/* ---- 2b. the chain index: every block behind the first change has (inserted - removed events below it) more entries
+		 * before it.  (The runs below search the OLD chain with the index: a row is patched by its own workgroup only, after
+		 * the runs have been planned ... so this happens at the very end, see step 8.) */
 		/* ---- 3. every group starts a run, writing its new entries into MGL_BATCH_RES entries of the span area taken for it
 		 * (most runs fit: a perturbed probability re-joins the old trajectory after about a hundred events; one that does not is
 		 * run again in step 5, into a place of its size) ... */
@@ -645,7 +659,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			const uint32_t at = atomicAdd(&ab.hdr[6], MGL_BATCH_RES);
 			s_gat[tid] = at;
 			if (at + MGL_BATCH_RES > ab.span_cap) s_fail = 1;
-			else s_run[tid] = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, ab.span_pos, ab.span_ev, at, MGL_BATCH_RES);
+			else s_run[tid] = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, ab.span_pos, ab.span_ev, at, MGL_BATCH_RES, sb_row, sb_info);
 		}
 		__syncthreads();
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
@@ -693,7 +707,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 				if (at + spn > ab.span_cap) s_fail = 1;
 				else {
 					s_hspan[tid] = at;
-					(void)batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, at, spn);
+					(void)batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, at, spn, sb_row, sb_info);
 				}
 			}
 			if (!s_fail && r0.uncoupled) { ab.span_pos[at + r0.ns] = MGL_POS_INF; ab.span_ev[at + r0.ns] = (uint16_t)r0.end_p; }
@@ -772,6 +786,20 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			if (tid == 0) {
 				b.ch_len[cx] = s_newlen;
 				if (moved) { b.ch_off[cx] = noff; b.ch_cap[cx] = s_newcap; }
+			}
+		}
+		/* ---- 6b. the chain index of this context (nothing searches the old chain any more) */
+		__syncthreads();
+		{
+			const uint32_t first = ((ni ? s_ipos[0] : MGL_POS_INF) < (nr ? s_rpos[0] : MGL_POS_INF)) ? s_ipos[0] : s_rpos[0];
+			for (uint32_t blk = (first >> b.sb_shift) + 1u + tid; blk <= b.nsb; blk += blockDim.x) {
+				const uint32_t bound = blk == b.nsb ? MGL_POS_INF : blk << b.sb_shift;
+				uint32_t a = 0, z = ni;
+				while (a < z) { const uint32_t m = (a + z) >> 1; if (s_ipos[m] < bound) a = m + 1; else z = m; }
+				const uint32_t di = a;
+				a = 0; z = nr;
+				while (a < z) { const uint32_t m = (a + z) >> 1; if (s_rpos[m] < bound) a = m + 1; else z = m; }
+				if (di != a) sb_row[blk] += di - a;
 			}
 		}
 		/* ---- 7. the runs go on a list: k_batch_ckpt patches this context's value in the dense checkpoints along each of them

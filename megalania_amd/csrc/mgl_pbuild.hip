@@ -540,6 +540,26 @@ __global__ void __launch_bounds__(256) pb_offsets(Base2 b, PBuild pb, uint32_t t
 	(void)total;
 }
 
+/* the chain index: pb.hist after pb_offsets is "events of the context in earlier blocks", row per block -- the index is its
+ * transpose, row per context (one more column: the chain's length) */
+__global__ void __launch_bounds__(256) pb_index(Base2 b, PBuild pb, uint32_t total)
+{
+	__shared__ uint32_t tile[32][33];
+	const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5; /* 32 x 8 */
+	const uint32_t c0 = blockIdx.x * 32u, b0 = blockIdx.y * 32u;
+	const size_t E = b.ck_elems;
+	for (uint32_t r = ty; r < 32u; r += 8u) {
+		const uint32_t blk = b0 + r, ctx = c0 + tx;
+		tile[r][tx] = (blk < pb.nblk && ctx < total) ? pb.hist[(size_t)blk * E + ctx] : 0u;
+	}
+	__syncthreads();
+	for (uint32_t r = ty; r < 32u; r += 8u) {
+		const uint32_t ctx = c0 + r, blk = b0 + tx;
+		if (ctx < total && blk < pb.nblk) b.ch_sb[(size_t)ctx * b.sb_stride + blk] = tile[tx][r];
+		if (ctx < total && blk == pb.nblk) b.ch_sb[(size_t)ctx * b.sb_stride + blk] = b.ch_len[ctx];
+	}
+}
+
 /* chain offsets; capacity = 2 len + 257 rounded up to 8 entries, as in k_build */
 __device__ __forceinline__ uint32_t pb_nseg(uint32_t len) { return len ? (len + MGL_PB_SEG - 1u) / MGL_PB_SEG : 1u; }
 __global__ void __launch_bounds__(64) pb_layout(Base2 b, PBuild pb, Control* ctl, uint32_t total)

@@ -151,6 +151,18 @@ def canonical_base(sa, slab):
     sp = np.unpackbits(sa.debug_dump(5, np.uint64).view(np.uint8), bitorder="little")[:n].astype(bool)
     st = sa.debug_dump(6, np.uint32).reshape(n, 8)[:, :5]
     ck = sa.debug_dump(7, np.uint16).reshape(-1, (total + 7) // 8 * 8)[:, :total]
+    # the chain index is checked against the chains it indexes, here, whoever built or patched it: entry [c][b] = entries of
+    # context c's chain with a position below b << shift (the last column: the chain's length)
+    shift = 8 if n <= (1 << 20) else 9 if n <= (1 << 23) else 10
+    nsb = (n + (1 << shift) - 1) >> shift
+    stride = (nsb + 2 + 3) & ~3
+    idx = sa.debug_dump(83, np.uint32).reshape(-1, stride)
+    bounds = (np.arange(nsb + 1, dtype=np.int64) << shift)
+    for c in range(total):
+        pos = chains[c][0][:-1].astype(np.int64)
+        want = np.searchsorted(pos, bounds, side="left")
+        want[nsb] = len(pos)
+        assert (idx[c, : nsb + 1] == want).all(), ("chain index", c, np.nonzero(idx[c, : nsb + 1] != want)[0][:5])
     return dict(chains=chains, on=on, sp=sp, st=st[sp], ck=ck)
 
 

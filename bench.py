@@ -163,6 +163,52 @@ def reference_curve(cfg):
         return json.load(f)
 
 
+def reference_spread(cfg):
+    """The compiled reference's own spread over srand seeds on this input (tests/golden/reference_spread_<cfg>.json,
+    MGL_CURVE_SEED=n tools/reference_curve.py): {iterations: [est_bytes per seed]}."""
+    path = os.path.join(ROOT, "tests", "golden", f"reference_spread_{cfg}.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        d = json.load(f)
+    out = {}
+    for run in d["runs"]:
+        for p in run["points"]:
+            out.setdefault(p["iterations"], []).append(p["est_bytes"])
+    return out
+
+
+def seed_spread_gate(binding, data, K, props, cfg, accept="auto", seeds=(1673551, 1673551 + 7919, 1673551 + 2 * 7919)):
+    """Equal evaluations, means over seeds on both sides: the device's chains (three seeds) against the reference's runs
+    (the golden curve's seed and those of reference_spread_<cfg>.json)."""
+    spread = reference_spread(cfg)
+    curve = reference_curve(cfg)
+    if not spread or not curve:
+        return None
+    for p in curve["points"]:
+        if p["iterations"] in spread:
+            spread[p["iterations"]] = spread[p["iterations"]] + [p["est_bytes"]]
+    marks = sorted(spread)
+    rows = {m: [] for m in marks}
+    n = len(data)
+    for sd in seeds:
+        sa = binding.SA(data, neighbours_per_step=K, seed=sd, iters_per_epoch=n, accept=accept, **props)
+        done = 0
+        for m in marks:
+            steps = -(-m // K)
+            st = sa.run(steps - done)
+            done = steps
+            rows[m].append(18 + st["best_cost"] / 16384)
+        sa.close()
+    out = []
+    for m in marks:
+        g, r = rows[m], spread[m]
+        out.append(dict(evaluations=m, gpu_seeds=len(g), gpu_mean=round(sum(g) / len(g), 1), gpu_min=round(min(g), 1), gpu_max=round(max(g), 1),
+                        reference_seeds=len(r), reference_mean=round(sum(r) / len(r), 1), reference_min=round(min(r), 1), reference_max=round(max(r), 1),
+                        gpu_mean_le_reference_mean=sum(g) / len(g) <= sum(r) / len(r), gpu_mean_le_reference_max=sum(g) / len(g) <= max(r)))
+    return out
+
+
 def size_gates(binding, data, K, props, cpu, cfg, accept="auto"):
     """Estimated stream size (18 + perplexity / 16384, main.c:97) of a fresh chain in the default accept mode against
     the reference path's at (a) equal evaluations and (b) equal steps = reference iterations, both stated."""
@@ -541,6 +587,9 @@ def main():
                 sg3 = size_gates(binding, c2, DEFAULT_K["c2"], {}, None, "c2", accept="bulk")
                 if sg3:
                     gates["size_vs_reference_c2_bulk"] = sg3
+                sg4 = seed_spread_gate(binding, c2, DEFAULT_K["c2"], {}, "c2")
+                if sg4:
+                    gates["size_vs_reference_c2_means_over_seeds"] = sg4
         if gates:
             out["gates"] = gates
         print(json.dumps(out), flush=True)

@@ -143,6 +143,7 @@ struct mgl_sa {
 	uint32_t* d_strat_tgt = nullptr;
 	uint32_t* d_strat_pre = nullptr; /* stratified targets: packets before every block of 4 096 positions */
 	bool select_small = false;    /* the previous bulk step had few acceptable neighbours: this one's selection runs as one launch */
+	uint32_t* h_bstat = nullptr;   /* pinned: the batch accept's status words, read back once per bulk step */
 	uint32_t force_batch_fail = 0; /* diagnostic (mgl_debug_set key 5): the next so many batch accepts give up behind their commit */
 	uint64_t batch_accepts = 0, batch_fallbacks = 0; /* bulk steps whose moves were patched in / that went to the rebuild although a batch accept began */
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
@@ -623,6 +624,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->d_todo); dfree(sa->d_prof);
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
+	if (sa->h_bstat) (void)hipHostFree(sa->h_bstat);
 	dfree(sa->big.cont); dfree(sa->d_traffic); dfree(sa->d_strat_pre); dfree(sa->d_strat_tgt);
 	{
 		BatchBuf& bt = sa->batch;
@@ -950,6 +952,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&bt.bk_rcl, MGL_BATCH_ALLOC));
 			HIPCHK(hipMalloc(&bt.acc, sizeof(long long) * 4));
 			HIPCHK(hipMemset(bt.acc, 0, sizeof(long long) * 4));
+			HIPCHK(hipHostMalloc((void**)&sa->h_bstat, sizeof(uint32_t) * 16, hipHostMallocDefault));
 			sa->batch_ok = sa->incremental_apply && getenv("MGL_NO_BATCH") == nullptr;
 
 		}
@@ -1372,8 +1375,9 @@ static int launch_bulk_tail(mgl_sa* sa)
 		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 1, (const uint32_t*)sa->batch.hdr);
 		hipLaunchKernelGGL(k_batch_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->batch);
 		HIPCHK(hipGetLastError());
-		HIPCHK(hipMemcpyAsync(bstat, sa->batch.hdr, sizeof bstat, hipMemcpyDeviceToHost, sa->stream));
+		HIPCHK(hipMemcpyAsync(sa->h_bstat, sa->batch.hdr, sizeof bstat, hipMemcpyDeviceToHost, sa->stream)); /* pinned: no staging copy */
 		HIPCHK(hipStreamSynchronize(sa->stream));
+		memcpy(bstat, sa->h_bstat, sizeof bstat);
 		if (sa->force_batch_fail) {
 			const uint32_t zero = 0u;
 			HIPCHK(hipMemcpy(sa->batch.hdr + 9, &zero, sizeof zero, hipMemcpyHostToDevice));

@@ -199,19 +199,20 @@ def test_incremental_accept_equals_rebuild(name, K, steps, golden, golden_input)
     ref.close()
 
 
-@pytest.mark.parametrize("name,K,steps", [("lorem4k", 96, 80), ("enwik3k", 128, 80), ("reps", 64, 80), ("zeros600", 32, 40)])
-def test_batch_accept_equals_rebuild(name, K, steps, golden, golden_input, monkeypatch):
+@pytest.mark.parametrize("name,K,steps,lcpb", [("lorem4k", 96, 80, {}), ("enwik3k", 128, 80, {}), ("reps", 64, 80, {}), ("zeros600", 32, 40, {}),
+                                               ("enwik3k", 128, 60, dict(lc=2, lp=1, pb=2))], ids=["lorem4k", "enwik3k", "reps", "zeros600", "enwik3k-lc2lp1pb2"])
+def test_batch_accept_equals_rebuild(name, K, steps, lcpb, golden, golden_input, monkeypatch):
     """Bulk steps that take at most MGL_BATCH_MAX moves patch the base for all of them at once (mgl_kernels5.hip) instead of
     re-deriving it: after every such step bitmaps, special-state records, chains and dense checkpoints are identical to a
     rebuild from the slab, the cost is the oracle's walk of the slab, and a chain with the batch path switched off
     (MGL_NO_BATCH: every bulk step a rebuild) walks the same trajectory."""
     data = golden_input(name)
-    inc = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=5, iters_per_epoch=10**7)
+    inc = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=5, iters_per_epoch=10**7, **lcpb)
     monkeypatch.setenv("MGL_NO_BATCH", "1")
-    full = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=5, iters_per_epoch=10**7)
+    full = binding.SA(data, accept="bulk", neighbours_per_step=K, seed=5, iters_per_epoch=10**7, **lcpb)
     monkeypatch.delenv("MGL_NO_BATCH")
-    ref = binding.SA(data, accept="single", neighbours_per_step=8, seed=5)
-    o = Oracle(data, dict_limit=0x400000)
+    ref = binding.SA(data, accept="single", neighbours_per_step=8, seed=5, **lcpb)
+    o = Oracle(data, dict_limit=0x400000, **lcpb)
     moves = multi = 0
     for s in range(steps):
         st, sf = inc.run(1), full.run(1)
@@ -230,7 +231,7 @@ def test_batch_accept_equals_rebuild(name, K, steps, golden, golden_input, monke
     assert ia >= 3                      # the batch path really ran
     assert full.batch_counters() == (0, 0)
     bst, _ = inc.best()
-    assert lzma.decompress(binding.emit_stream(data, bst), format=lzma.FORMAT_ALONE) == data
+    assert lzma.decompress(binding.emit_stream(data, bst, **lcpb), format=lzma.FORMAT_ALONE) == data
     inc.close(); full.close(); ref.close()
 
 

@@ -386,6 +386,21 @@ def test_c4_shape_100_mb():
             got = [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in diffs[j][: nd[j]]]
             assert got == [(int(d["position"]), as_list([d["old"]])[0], as_list([d["new"]])[0]) for d in od], j
     sa.close()
+    # the batch accept at this size (chains of 10^7 entries rewritten in place, hundreds of chunks per stretch): a step of few
+    # neighbours on the greedy-seeded slab takes few moves, so every bulk step patches them in; the patched structures give
+    # the cost an independent CPU walk gives, and the cost a rebuild from the slab gives
+    sb = binding.SA(data, neighbours_per_step=192, seed=seed, iters_per_epoch=n, accept="bulk")
+    sb.seed_greedy(64)
+    moves = 0
+    for s in range(6):
+        moves += sb.run(1)["accepted"]
+    assert sb.batch_counters()[0] >= 4 and sb.batch_counters()[1] == 0 and moves > 20
+    cur, cost = sb.current()
+    slab = np.ascontiguousarray(cur).astype(literal_slab(1).dtype)
+    assert cost == o.cost_slab(slab)["total"]
+    sb.set_slab(cur)
+    assert sb.current()[1] == cost
+    sb.close()
 
 
 @pytest.mark.parametrize("cfg,size", [("c2", 100000), ("c5", 200000), ("c1", 4096), ("c2", 4097), ("c2", 2), ("c2", 3)])

@@ -7,8 +7,9 @@ from megalania_amd import binding, corpus
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 accept = sys.argv[3] if len(sys.argv) > 3 else "auto"
-K = {"c1": 1024, "c2": 4096, "c3": 16384}[cfg]
-marks = [8, 25, 74, 245] if cfg == "c2" else [62, 256]
+K0 = {"c1": 1024, "c2": 4096, "c3": 16384}[cfg]
+K = int(os.environ.get("MGL_K", K0))  # (MGL_K: another step size at the same evaluation marks)
+marks = [m * K0 // K for m in ([8, 25, 74, 245] if cfg == "c2" else [62, 256])]
 data, _ = corpus.config_input(cfg)
 rows = []
 for sd in range(seeds):
@@ -21,4 +22,4 @@ for sd in range(seeds):
     sa.close()
 for i, m in enumerate(marks):
     v = [r[i][1] for r in rows]
-    print(f"{cfg} {accept} steps {m:4d} evaluations {rows[0][i][0]:8d}: mean {sum(v)/len(v):9.1f}  min {min(v):9.1f} max {max(v):9.1f}")
+    print(f"{cfg} K={K} {accept} steps {m:4d} evaluations {rows[0][i][0]:8d}: mean {sum(v)/len(v):9.1f}  min {min(v):9.1f} max {max(v):9.1f}")

@@ -28,11 +28,6 @@
 #define MGL_BIG_CAP 4096u   /* the same, per flagged neighbour, in the global scratch of the second pass: a neighbour that inserts
                             * or removes more events than this is dropped (the oracle counts the same events) */
 #define MGL_BULK_ROUNDS 8u /* rounds of the bulk selection (mgl_kernels4.hip:k_bulk_round); mirrored by the oracle */
-#define MGL_MAX_REPAIR_PICKS 8u /* top-K picks one neighbour's repair may need before it is given up and dropped (every one is a model
-                                * reconstruction + a top-K query in the middle of the walk); the oracle counts the same picks */
-#define MGL_MAX_WALK 512u   /* neighbour packets the two-pointer walk visits (skipped literal runs do not count) before the neighbour is
-                            * given up and dropped: rep distances that no match ever flushes (long runs coded as rep matches) keep two
-                            * walks apart for kilobytes; the oracle counts the same packets */
 #ifndef MGL_NBR_WAVES_PER_SIMD
 #define MGL_NBR_WAVES_PER_SIMD 2 /* register budget of the neighbour kernel: 2 -> 256 VGPRs, no scratch; 3 -> 168 VGPRs
                                     but 200 B/lane of scratch (52 MB of spill traffic per launch) for the same speed */

@@ -19,6 +19,11 @@
 #define MGL_WAVE 64
 #define MGL_CKPT_SHIFT 10u          /* one prefix checkpoint per 1024 input bytes */
 #define MGL_MAX_DIFFS 64u           /* journal capacity per neighbour */
+#define MGL_MAX_REPAIR_PICKS 8u /* top-K picks one neighbour's repair may need before it is given up and dropped (every one is a model
+                                * reconstruction + a top-K query in the middle of the walk); the oracle counts the same picks */
+#define MGL_MAX_WALK 2048u   /* neighbour packets the two-pointer walk visits (skipped literal runs do not count) before the neighbour is
+                            * given up and dropped: rep distances that no match ever flushes (long runs coded as rep matches) keep two
+                            * walks apart for kilobytes; the oracle counts the same packets */
 #define MGL_MAX_TOPK 32u
 #define MGL_PRICE_WORDS 1072u         /* top-K price tables per wavefront (u32): 2x272 lengths, 4x64 slots, 128 tails, 16 align, 64 slot bounds, 64 suffix minima */
 #define MGL_SEQ_MASK ((1ull << 44) - 1ull)

@@ -812,7 +812,7 @@ __device__ WinInfo window_end_from_journal(const DevCtx& c, const mgl_pk* slab, 
 			}
 		}
 		if (nb.pos >= c.n && bs.pos >= c.n) { wend = c.n; break; }
-		if (walked > 512u) break; /* MGL_MAX_WALK */
+		if (walked > MGL_MAX_WALK) break;
 		if (nb.pos <= bs.pos && nb.pos < c.n) {
 			if (!first && count < 8) count++;
 			first = false;
@@ -1013,7 +1013,7 @@ __device__ void nbr_fullwalk_one(const DevCtx& c, const BaseView& b, const Contr
 	}
 	const WinInfo wi = window_end_from_journal(c, b.slab, jn, st_target, lane);
 	const uint32_t wend = wi.end;
-	if (wi.n_ins > 4096u || wi.n_rem > 4096u || wi.walked > 512u || npicks > 8u) { /* MGL_BIG_CAP / MGL_MAX_WALK / MGL_MAX_REPAIR_PICKS: what the incremental engine's lists hold, its walk visits, its repair picks */
+	if (wi.n_ins > 4096u || wi.n_rem > 4096u || wi.walked > MGL_MAX_WALK || npicks > MGL_MAX_REPAIR_PICKS) { /* MGL_BIG_CAP / MGL_MAX_WALK / MGL_MAX_REPAIR_PICKS: what the incremental engine's lists hold, its walk visits, its repair picks */
 		if (lane == 0) { out.cost[j] = MGL_INVALID_COST; out.ndiffs[j] = 0; out.walked[j] = w.packets - first_packet; out.win[2u * j] = target; out.win[2u * j + 1u] = MGL_WIN_DROPPED; }
 		return;
 	}

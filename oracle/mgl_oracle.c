@@ -812,7 +812,7 @@ int orc_sa_iters(orc_ctx* c, orc_packet* slab, orc_packet* best, uint64_t* cur_i
 #define ORC_MAX_EVENTS 4096
 #define ORC_BULK_ROUNDS 8u
 #define ORC_MAX_REPAIR_PICKS 8 /* top-K picks the repair of one neighbour may need (invalid LONG_REPs, packet_slab_neighbour.c:99-109) */
-#define ORC_MAX_WALK 512 /* neighbour packets the device's two-pointer walk visits before it gives a neighbour up */
+#define ORC_MAX_WALK 2048 /* neighbour packets the device's two-pointer walk visits before it gives a neighbour up */
 static uint64_t mix64(uint64_t z)
 {
 	z += 0x9E3779B97F4A7C15ull;

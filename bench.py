@@ -178,6 +178,30 @@ def reference_spread(cfg):
     return out
 
 
+def run_to_marks(sa, K, ev_marks, st_marks=()):
+    """Run a chain until it has made each number of evaluations in `ev_marks` -- successful ones, as the reference's
+    iteration counter counts them (main.c:81-84 retries a failed generate without counting it) -- and each number of
+    steps in `st_marks`; returns {mark: (est_bytes, evaluations, steps)} for both."""
+    ev_marks, st_marks = sorted(set(ev_marks)), sorted(set(st_marks))
+    at_ev, at_st, done, evals, est = {}, {}, 0, 0, None
+    while True:
+        while ev_marks and evals >= ev_marks[0]:
+            at_ev[ev_marks.pop(0)] = (est, evals, done)
+        while st_marks and done >= st_marks[0]:
+            at_st[st_marks.pop(0)] = (est, evals, done)
+        if not ev_marks and not st_marks:
+            return at_ev, at_st
+        want = []
+        if ev_marks:
+            want.append(max(1, -(-(ev_marks[0] - evals) // K)))
+        if st_marks:
+            want.append(st_marks[0] - done)
+        st = sa.run(min(want))
+        done += st["steps"]
+        evals += st["evaluations"]
+        est = 18 + st["best_cost"] / 16384
+
+
 def seed_spread_gate(binding, data, K, props, cfg, accept="auto", seeds=(1673551, 1673551 + 7919, 1673551 + 2 * 7919)):
     """Equal evaluations, means over seeds on both sides: the device's chains (three seeds) against the reference's runs
     (the golden curve's seed and those of reference_spread_<cfg>.json)."""
@@ -190,20 +214,19 @@ def seed_spread_gate(binding, data, K, props, cfg, accept="auto", seeds=(1673551
             spread[p["iterations"]] = spread[p["iterations"]] + [p["est_bytes"]]
     marks = sorted(spread)
     rows = {m: [] for m in marks}
+    evs = {m: [] for m in marks}
     n = len(data)
     for sd in seeds:
         sa = binding.SA(data, neighbours_per_step=K, seed=sd, iters_per_epoch=n, accept=accept, **props)
-        done = 0
+        at_ev, _ = run_to_marks(sa, K, marks)
         for m in marks:
-            steps = -(-m // K)
-            st = sa.run(steps - done)
-            done = steps
-            rows[m].append(18 + st["best_cost"] / 16384)
+            rows[m].append(at_ev[m][0])
+            evs[m].append(at_ev[m][1])
         sa.close()
     out = []
     for m in marks:
         g, r = rows[m], spread[m]
-        out.append(dict(evaluations=m, gpu_seeds=len(g), gpu_mean=round(sum(g) / len(g), 1), gpu_min=round(min(g), 1), gpu_max=round(max(g), 1),
+        out.append(dict(evaluations=m, gpu_evaluations=evs[m], gpu_seeds=len(g), gpu_mean=round(sum(g) / len(g), 1), gpu_min=round(min(g), 1), gpu_max=round(max(g), 1),
                         reference_seeds=len(r), reference_mean=round(sum(r) / len(r), 1), reference_min=round(min(r), 1), reference_max=round(max(r), 1),
                         gpu_mean_le_reference_mean=sum(g) / len(g) <= sum(r) / len(r), gpu_mean_le_reference_max=sum(g) / len(g) <= max(r)))
     return out
@@ -225,25 +248,19 @@ def size_gates(binding, data, K, props, cpu, cfg, accept="auto"):
     budget = CONFIG_ITERS.get(cfg)
     if budget and all(it != budget for it, _, _ in pts):
         pts.append((budget, None, "no reference figure: BASELINE.json's iteration budget for this config (the reference path would need days)"))
-    marks = sorted({-(-it // K) for it, _, _ in pts} | {it for it, _, _ in pts if it <= 4096})
     sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=n, accept=accept, **props)
-    at, done, evals = {}, 0, 0
-    for m in marks:
-        st = sa.run(m - done)
-        done = m
-        evals += st["evaluations"]
-        at[m] = (18 + st["best_cost"] / 16384, evals)
+    at_ev, at_st = run_to_marks(sa, K, [it for it, _, _ in pts], [it for it, ref, _ in pts if it <= 4096 and ref is not None])
     sa.close()
     out = []
     for it, ref_bytes, src in pts:
-        s_eq = -(-it // K)
+        est, evals, steps = at_ev[it]
         row = dict(reference_iterations=it, reference_est_bytes=None if ref_bytes is None else round(ref_bytes, 1), reference_source=src, accept_mode=accept,
                    config_budget=(it == budget),
-                   equal_evaluations=dict(gpu_steps=s_eq, gpu_evaluations=at[s_eq][1], gpu_est_bytes=round(at[s_eq][0], 1),
-                                          gpu_le_reference=None if ref_bytes is None else at[s_eq][0] <= ref_bytes))
-        if it in at and ref_bytes is not None:
-            row["equal_steps"] = dict(gpu_steps=it, gpu_evaluations=at[it][1], gpu_est_bytes=round(at[it][0], 1),
-                                      gpu_le_reference=at[it][0] <= ref_bytes)
+                   equal_evaluations=dict(gpu_steps=steps, gpu_evaluations=evals, gpu_est_bytes=round(est, 1),
+                                          gpu_le_reference=None if ref_bytes is None else est <= ref_bytes))
+        if it in at_st:
+            est, evals, steps = at_st[it]
+            row["equal_steps"] = dict(gpu_steps=steps, gpu_evaluations=evals, gpu_est_bytes=round(est, 1), gpu_le_reference=est <= ref_bytes)
         out.append(row)
     return out
 

@@ -144,6 +144,7 @@ struct mgl_sa {
 	uint32_t* d_strat_pre = nullptr; /* stratified targets: packets before every block of 4 096 positions */
 	bool select_small = false;    /* the previous bulk step had few acceptable neighbours: this one's selection runs as one launch */
 	uint32_t* h_bstat = nullptr;   /* pinned: the batch accept's status words, read back once per bulk step */
+	hipEvent_t ev_bstat = nullptr; /* behind that read-back's copy */
 	uint32_t force_batch_fail = 0; /* diagnostic (mgl_debug_set key 5): the next so many batch accepts give up behind their commit */
 	uint64_t batch_accepts = 0, batch_fallbacks = 0; /* bulk steps whose moves were patched in / that went to the rebuild although a batch accept began */
 	std::vector<uint8_t> mode_log; /* per step of the last mgl_sa_run: 0 single, 1 bulk */
@@ -625,6 +626,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	dfree(sa->big.sim_hdr); dfree(sa->big.sim_keys); dfree(sa->big.sim_pos);
 	dfree(sa->big.ins_key); dfree(sa->big.rem_key); dfree(sa->big.ins_pos); dfree(sa->big.rem_pos); dfree(sa->big.uctx);
 	if (sa->h_bstat) (void)hipHostFree(sa->h_bstat);
+	if (sa->ev_bstat) (void)hipEventDestroy(sa->ev_bstat);
 	dfree(sa->big.cont); dfree(sa->d_traffic); dfree(sa->d_strat_pre); dfree(sa->d_strat_tgt);
 	{
 		BatchBuf& bt = sa->batch;
@@ -953,6 +955,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			HIPCHK(hipMalloc(&bt.acc, sizeof(long long) * 4));
 			HIPCHK(hipMemset(bt.acc, 0, sizeof(long long) * 4));
 			HIPCHK(hipHostMalloc((void**)&sa->h_bstat, sizeof(uint32_t) * 16, hipHostMallocDefault));
+			HIPCHK(hipEventCreateWithFlags(&sa->ev_bstat, hipEventDisableTiming));
 			sa->batch_ok = sa->incremental_apply && getenv("MGL_NO_BATCH") == nullptr;
 
 		}
@@ -1340,6 +1343,21 @@ static DecideArgs decide_args(const mgl_sa* sa)
 	a.sqrt_thresh = sa->sqrt_thresh; a.temperature = sa->temperature;
 	return a;
 }
+/* what closes a bulk step: best-slab tracking, the step's counters.  `gate` = the batch accept's status word when these
+ * are queued before the host has read it (they then run beside the read-back), nullptr when the host knows the step is in */
+static void launch_bulk_close(mgl_sa* sa, const uint32_t* gate)
+{
+	hipLaunchKernelGGL(k_bulk_finish, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, sa->snapshots ? 1 : 0,
+	                   sa->snapshots ? &sa->d_snap_meta[1].valid : (uint32_t*)nullptr, gate);
+	if (sa->snapshots) {
+		hipLaunchKernelGGL(k_bulk_keep_copy, dim3(1024), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n, gate);
+		hipLaunchKernelGGL(k_bulk_keep_undo, dim3(64), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->d_best, gate);
+	} else {
+		hipLaunchKernelGGL(k_bulk_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n, gate);
+	}
+	hipLaunchKernelGGL(k_bulk_reset, dim3(1), dim3(64), 0, sa->stream, sa->bulk, gate);
+	hipLaunchKernelGGL(k_bulk_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->d_counts, sa->form_single ? 1 : 0, gate);
+}
 /* the tail of a bulk step: selection, journals into the slab, parallel rebuild, best-slab tracking */
 static int launch_bulk_tail(mgl_sa* sa)
 {
@@ -1359,6 +1377,7 @@ static int launch_bulk_tail(mgl_sa* sa)
 	/* A step that took few moves patches the base structures for all of them at once (mgl_kernels5.hip); every kernel of
 	 * that looks at the status word first, so a step that took none, or too many, passes through in a few microseconds. */
 	uint32_t bstat[8] = { 2u, 0, 0, 0, 0, 0, 0, 0 }; /* without the batch path: everything is the rebuild's */
+	bool closed = false; /* the closing kernels are queued (behind the batch accept's gate) and the gate is open */
 	if (sa->batch_ok && !sa->force_rollbacks) { /* (the rollback net hangs under the rebuild: while a test forces it, steps go that way) */
 		Base2& b = sa->b2;
 		if (sa->force_batch_fail) { const uint32_t one = 1u; HIPCHK(hipMemcpyAsync(sa->batch.hdr + 9, &one, sizeof one, hipMemcpyHostToDevice, sa->stream)); }
@@ -1376,8 +1395,12 @@ static int launch_bulk_tail(mgl_sa* sa)
 		hipLaunchKernelGGL(k_batch_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->batch);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipMemcpyAsync(sa->h_bstat, sa->batch.hdr, sizeof bstat, hipMemcpyDeviceToHost, sa->stream)); /* pinned: no staging copy */
-		HIPCHK(hipStreamSynchronize(sa->stream));
+		HIPCHK(hipEventRecord(sa->ev_bstat, sa->stream));
+		launch_bulk_close(sa, (const uint32_t*)sa->batch.hdr); /* behind the gate: they run while the host reads the status */
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventSynchronize(sa->ev_bstat));
 		memcpy(bstat, sa->h_bstat, sizeof bstat);
+		closed = bstat[0] == 3u || bstat[0] == 0u;
 		if (sa->force_batch_fail) {
 			const uint32_t zero = 0u;
 			HIPCHK(hipMemcpy(sa->batch.hdr + 9, &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -1416,16 +1439,7 @@ static int launch_bulk_tail(mgl_sa* sa)
 			if ((rc = launch_pbuild(sa))) return rc;
 		}
 	}
-	hipLaunchKernelGGL(k_bulk_finish, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->bulk, sa->snapshots ? 1 : 0,
-	                   sa->snapshots ? &sa->d_snap_meta[1].valid : (uint32_t*)nullptr);
-	if (sa->snapshots) {
-		hipLaunchKernelGGL(k_bulk_keep_copy, dim3(1024), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
-		hipLaunchKernelGGL(k_bulk_keep_undo, dim3(64), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, sa->nbr, sa->bulk, sa->d_best);
-	} else {
-		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl, (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
-	}
-	hipLaunchKernelGGL(k_bulk_reset, dim3(1), dim3(64), 0, sa->stream, sa->bulk);
-	hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, 0, sa->d_counts, 0, sa->form_single ? 1 : 0);
+	if (!closed) launch_bulk_close(sa, nullptr);
 	HIPCHK(hipGetLastError());
 	return MGL_OK;
 }

@@ -350,9 +350,13 @@ __global__ void k_bulk_end(Control* ctl, BulkBuf bb, DecideArgs a)
  * when a bulk step leaves the best slab (rare: it took moves and their sum did not improve) the
  * best slab itself is restored from the new one and the undo log (k_bulk_keep_*), and its
  * structures are re-derived when an epoch next starts from it. */
-__global__ void k_bulk_finish(Control* ctl, BulkBuf bb, int lazy_best, uint32_t* snap_best_valid)
+/* The kernels that close a bulk step take a gate: the batch accept's status word (mgl_kernels5.hip).  They are queued
+ * behind the batch accept before the host has read that word, so that they run while it does: they go ahead when the
+ * moves are in (3) or the step took none (0); a step that goes to the rebuild instead queues them again, ungated. */
+__device__ __forceinline__ bool gate_open(const uint32_t* gate) { return gate == nullptr || gate[0] == 3u || gate[0] == 0u; }
+__global__ void k_bulk_finish(Control* ctl, BulkBuf bb, int lazy_best, uint32_t* snap_best_valid, const uint32_t* gate)
 {
-	if (threadIdx.x || blockIdx.x) return;
+	if (threadIdx.x || blockIdx.x || !gate_open(gate)) return;
 	const uint32_t taken = ctl->taken;
 	if (taken) {
 		ctl->cur_cost = ctl->rebuild_cost;
@@ -375,14 +379,15 @@ __global__ void k_bulk_finish(Control* ctl, BulkBuf bb, int lazy_best, uint32_t*
 	bb.hdr[2] = bb.hdr[3] = bb.hdr[4] = bb.hdr[5] = 0; bb.hdr[6] = ~0ull;
 }
 /* best slab := the slab before this step = the new slab ... */
-__global__ void __launch_bounds__(256) k_bulk_keep_copy(const Control* ctl, const mgl_pk* slab, mgl_pk* best, uint32_t n)
+__global__ void __launch_bounds__(256) k_bulk_keep_copy(const Control* ctl, const mgl_pk* slab, mgl_pk* best, uint32_t n, const uint32_t* gate)
 {
-	if (!ctl->bulk_need_undo) return;
+	if (!gate_open(gate) || !ctl->bulk_need_undo) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) best[i] = slab[i];
 }
 /* ... with the taken journals undone */
-__global__ void __launch_bounds__(256) k_bulk_keep_undo(const Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* best)
+__global__ void __launch_bounds__(256) k_bulk_keep_undo(const Control* ctl, NbrOut out, BulkBuf bb, mgl_pk* best, const uint32_t* gate)
 {
+	if (!gate_open(gate)) return;
 	const uint32_t taken = (uint32_t)bb.hdr[1];
 	if (ctl->bulk_need_undo) {
 		for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < taken; t += gridDim.x * blockDim.x) {
@@ -401,9 +406,19 @@ __global__ void __launch_bounds__(256) k_bulk_rollback(NbrOut out, BulkBuf bb, m
 		for (uint32_t e = 0; e < nd; e++) slab[out.dpos[(size_t)j * MGL_MAX_DIFFS + e]] = out.dold[(size_t)j * MGL_MAX_DIFFS + e];
 	}
 }
-__global__ void k_bulk_reset(BulkBuf bb)
+__global__ void k_bulk_reset(BulkBuf bb, const uint32_t* gate)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0) bb.hdr[1] = 0;
+	if (threadIdx.x == 0 && blockIdx.x == 0 && gate_open(gate)) bb.hdr[1] = 0;
+}
+/* the slab copy of a new best, for handles without snapshots (k_copy_best behind the gate) */
+__global__ void __launch_bounds__(256) k_bulk_copy_best(const Control* ctl, const mgl_pk* slab, mgl_pk* best, uint32_t n, const uint32_t* gate)
+{
+	if (!gate_open(gate) || !ctl->copy_best_flag) return;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) best[i] = slab[i];
+}
+__global__ void k_bulk_step_end(Control* ctl, uint32_t* counts, int form_single, const uint32_t* gate)
+{
+	if (gate_open(gate)) step_end_body(ctl, 0, counts, 0, form_single);
 }
 
 /* ================================================================== look-ahead

@@ -41,7 +41,10 @@
 #define MGL_BATCH_EVCAP 4096u  /* inserted / removed events staged per cluster */
 #define MGL_BATCH_OPCAP 2048u  /* bitmap / state-record ops per cluster */
 #define MGL_BATCH_SUB 1024u    /* events of one kind per context */
-#define MGL_BATCH_RES 256u     /* entries of the span area every run gets to begin with */
+#define MGL_BATCH_RES 256u     /* entries of the span area every run gets to begin with ... */
+#define MGL_BATCH_RES_FEW 1024u /* ... when the step has at most MGL_BATCH_FEW clusters (the evolved slab's steps: a run of the distance-align or slot-root
+                                * contexts -- near-random bits -- takes several hundred events to re-join, and one that does not fit runs twice) */
+#define MGL_BATCH_FEW 32u
 #define MGL_BATCH_GAP 32u      /* events of a context further apart than this start a group of their own */
 #define MGL_BATCH_ALLOC (MGL_BATCH_MAX * MGL_BATCH_EVCAP) /* entries of the combined event lists (ApplyBuf lists are allocated this long) */
 
@@ -655,11 +658,12 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		/* ---- 3. every group starts a run, writing its new entries into MGL_BATCH_RES entries of the span area taken for it
 		 * (most runs fit: a perturbed probability re-joins the old trajectory after about a hundred events; one that does not is
 		 * run again in step 5, into a place of its size) ... */
+		const uint32_t res = bt.hdr[1] <= MGL_BATCH_FEW ? MGL_BATCH_RES_FEW : MGL_BATCH_RES;
 		if (tid < ng) {
-			const uint32_t at = atomicAdd(&ab.hdr[6], MGL_BATCH_RES);
+			const uint32_t at = atomicAdd(&ab.hdr[6], res);
 			s_gat[tid] = at;
-			if (at + MGL_BATCH_RES > ab.span_cap) s_fail = 1;
-			else s_run[tid] = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, ab.span_pos, ab.span_ev, at, MGL_BATCH_RES, sb_row, sb_info);
+			if (at + res > ab.span_cap) s_fail = 1;
+			else s_run[tid] = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, ab.span_pos, ab.span_ev, at, res, sb_row, sb_info);
 		}
 		__syncthreads();
 		if (s_fail) { if (tid == 0) ctl->apply_failed = 1; return; }
@@ -670,7 +674,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			for (uint32_t g = 0; g < ng; g = s_run[g].last_group + 1u) {
 				const uint32_t spn = s_run[g].ns + (s_run[g].uncoupled ? 1u : 0u); /* + the new sentinel */
 				s_hlist[nh] = g;
-				s_hspan[nh] = spn <= MGL_BATCH_RES ? s_gat[g] : 0xFFFFFFFFu; /* where the run's entries are (absolute); 0xFFFFFFFF: to be written in step 5 */
+				s_hspan[nh] = spn <= res ? s_gat[g] : 0xFFFFFFFFu; /* where the run's entries are (absolute); 0xFFFFFFFF: to be written in step 5 */
 				d += (int32_t)s_run[g].ns - (int32_t)(s_run[g].k_end - s_run[g].k_start);
 				s_hdelta[nh] = d;
 				const uint32_t adl = (uint32_t)(d < 0 ? -d : d);
@@ -799,7 +803,7 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 				const uint32_t di = a;
 				a = 0; z = nr;
 				while (a < z) { const uint32_t m = (a + z) >> 1; if (s_rpos[m] < bound) a = m + 1; else z = m; }
-				if (di != a) sb_row[blk] += di - a;
+				if (di != a) atomicAdd(&sb_row[blk], di - a); /* (no value comes back: the thread does not wait for the row) */
 			}
 		}
 		/* ---- 7. the runs go on a list: k_batch_ckpt patches this context's value in the dense checkpoints along each of them

@@ -379,7 +379,7 @@ def test_c4_shape_100_mb():
     slab = np.ascontiguousarray(cur).astype(literal_slab(1).dtype)
     assert cost == o.cost_slab(slab)["total"]
     costs, nd, diffs = sa.neighbours(77)
-    for j in (5, 9000):
+    for j in (5, 9000, 123, 4567, 12000, 16383):
         ok, c, od = o.neighbour(slab, seed, 77, j, keep=False, K=K)
         assert int(costs[j]) == (c if ok else binding.INVALID_COST), j
         if ok:

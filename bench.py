@@ -306,6 +306,11 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    # stdout carries the one JSON line and nothing else: whatever libraries write to descriptor 1 meanwhile (gloo's connection
+    # notes, a make run of the in-tree build) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -609,7 +614,7 @@ def main():
                     gates["size_vs_reference_c2_means_over_seeds"] = sg4
         if gates:
             out["gates"] = gates
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     else:
         sa.close()
     if comm is not None:

@@ -64,6 +64,8 @@ struct mgl_sa {
 	hipStream_t stream;
 	hipStream_t stream2;     /* second half of a step's neighbours: its kernels fill the other half's tails */
 	hipEvent_t ev_fork, ev_join;
+	hipEvent_t ev_tgt = nullptr, ev_tgt_go = nullptr; /* the next step's targets worked out beside the rest of this step's accept (launch_targets_ahead) */
+	int tgt_ahead = 0;             /* 0 none, 1 queued and good for the next launch_neighbours, 2 queued but the base went another way: to be made again */
 	hipStream_t stream3 = nullptr;   /* the re-simulation kernels of the split form: beside the second pass, which only needs the walks */
 	hipEvent_t ev_rest[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }, ev_sim = nullptr;
 	uint32_t halves;
@@ -343,7 +345,8 @@ static int launch_validate(mgl_sa* sa)
 	return MGL_OK;
 }
 /* incremental engine, after k_decide: fold the winner into the base structures */
-static int launch_apply(mgl_sa* sa)
+static int launch_targets_ahead(mgl_sa* sa, uint64_t next_gstep);
+static int launch_apply(mgl_sa* sa, uint64_t next_gstep = ~0ull)
 {
 	/* the base is about to leave the best slab it still holds: keep a copy first (lazy: while every
 	 * accepted step is a new best no copy is ever taken) */
@@ -352,6 +355,7 @@ static int launch_apply(mgl_sa* sa)
 		if (rc) return rc;
 	}
 	hipLaunchKernelGGL(k_apply_walk, dim3(1), dim3(64), 0, sa->stream, sa->ctx, sa->b2, sa->base.ctl, sa->nbr, sa->ab);
+	if (next_gstep != ~0ull) { int rc = launch_targets_ahead(sa, next_gstep); if (rc) return rc; } /* the bitmap is final from here on */
 	if (!sa->snapshots)
 		hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
 		                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);
@@ -431,15 +435,38 @@ static int launch_lookahead(mgl_sa* sa, uint64_t gstep_next, bool after_check)
 	sa->la_ready = true;
 	return MGL_OK;
 }
+/* stratified targets of a step: packets before every block of 4 096 positions of the current walk, their
+ * prefix sums, then one wavefront per neighbour turns its ordinal into a position */
+static void launch_targets(mgl_sa* sa, hipStream_t st, uint64_t step_override)
+{
+	const uint32_t K = sa->cfg.neighbours_per_step;
+	const uint64_t* onwalk = sa->incremental ? sa->b2.onwalk : sa->base.v.onwalk;
+	const uint32_t nw0 = sa->incremental ? sa->b2.nw0 : (sa->ctx.n + 63u) >> 6;
+	hipLaunchKernelGGL(k_rank_blocks, dim3(sa->ctx.strat_nblk), dim3(64), 0, st, onwalk, nw0, sa->d_strat_pre, sa->ctx.strat_nblk);
+	hipLaunchKernelGGL(k_rank_scan, dim3(1), dim3(1024), 0, st, sa->d_strat_pre, sa->ctx.strat_nblk);
+	hipLaunchKernelGGL(k_targets, dim3((K + 3u) / 4u), dim3(256), 0, st, sa->ctx, onwalk, nw0, (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->d_strat_tgt);
+}
+/* The next step's targets need the on-walk bitmap of the new base and nothing else: an accept has written it long before it is
+ * through with chains and checkpoints, so they are worked out on the second stream beside the rest of the accept (30 us off
+ * every step).  Called right behind the launch that completes the bitmap; `next_gstep` is the step they are for. */
+static int launch_targets_ahead(mgl_sa* sa, uint64_t next_gstep)
+{
+	if (!sa->d_strat_pre || !sa->incremental) return MGL_OK;
+	HIPCHK(hipEventRecord(sa->ev_tgt_go, sa->stream));
+	HIPCHK(hipStreamWaitEvent(sa->stream2, sa->ev_tgt_go, 0));
+	launch_targets(sa, sa->stream2, next_gstep);
+	HIPCHK(hipEventRecord(sa->ev_tgt, sa->stream2));
+	HIPCHK(hipGetLastError());
+	sa->tgt_ahead = 1;
+	return MGL_OK;
+}
 static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_counts = true, bool from_lookahead = false)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
-	if (sa->d_strat_pre) { /* stratified targets: packets before every block of 4 096 positions of the current walk */
-		const uint64_t* onwalk = sa->incremental ? sa->b2.onwalk : sa->base.v.onwalk;
-		const uint32_t nw0 = sa->incremental ? sa->b2.nw0 : (sa->ctx.n + 63u) >> 6;
-		hipLaunchKernelGGL(k_rank_blocks, dim3(sa->ctx.strat_nblk), dim3(64), 0, sa->stream, onwalk, nw0, sa->d_strat_pre, sa->ctx.strat_nblk);
-		hipLaunchKernelGGL(k_rank_scan, dim3(1), dim3(1024), 0, sa->stream, sa->d_strat_pre, sa->ctx.strat_nblk);
-		hipLaunchKernelGGL(k_targets, dim3((K + 3u) / 4u), dim3(256), 0, sa->stream, sa->ctx, onwalk, nw0, (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->d_strat_tgt);
+	if (sa->d_strat_pre) {
+		if (sa->tgt_ahead) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_tgt, 0)); /* made beside the previous step's accept (or at least out of the buffers' way) */
+		if (sa->tgt_ahead != 1) launch_targets(sa, sa->stream, step_override);
+		sa->tgt_ahead = 0;
 	}
 	if (!sa->incremental) {
 		const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
@@ -650,6 +677,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	if (sa->ev_sim) (void)hipEventDestroy(sa->ev_sim);
 	if (sa->ev_val) (void)hipEventDestroy(sa->ev_val);
 	if (sa->ev_fork) (void)hipEventDestroy(sa->ev_fork);
+	if (sa->ev_tgt) (void)hipEventDestroy(sa->ev_tgt);
+	if (sa->ev_tgt_go) (void)hipEventDestroy(sa->ev_tgt_go);
 	if (sa->ev_join) (void)hipEventDestroy(sa->ev_join);
 	if (sa->stream) (void)hipStreamDestroy(sa->stream);
 	delete sa;
@@ -662,6 +691,8 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipStreamCreate(&sa->stream2));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_fork, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_join, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&sa->ev_tgt, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&sa->ev_tgt_go, hipEventDisableTiming));
 	HIPCHK(hipStreamCreate(&sa->stream3));
 	for (auto& e : sa->ev_rest) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_sim, hipEventDisableTiming));
@@ -1359,7 +1390,7 @@ static void launch_bulk_close(mgl_sa* sa, const uint32_t* gate)
 	hipLaunchKernelGGL(k_bulk_step_end, dim3(1), dim3(64), 0, sa->stream, sa->base.ctl, sa->d_counts, sa->form_single ? 1 : 0, gate);
 }
 /* the tail of a bulk step: selection, journals into the slab, parallel rebuild, best-slab tracking */
-static int launch_bulk_tail(mgl_sa* sa)
+static int launch_bulk_tail(mgl_sa* sa, uint64_t next_gstep)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
 	const DecideArgs a = decide_args(sa);
@@ -1386,6 +1417,8 @@ static int launch_bulk_tail(mgl_sa* sa)
 		hipLaunchKernelGGL(k_batch_commit, dim3(MGL_BATCH_MAX), dim3(256), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
 		hipLaunchKernelGGL(pb_levels, dim3((b.nw0 + 255) / 256), dim3(256), 0, sa->stream, (const uint64_t*)b.sp0, b.sp1, b.nw0, b.nw1);
 		hipLaunchKernelGGL(pb_levels, dim3((b.nw1 + 255) / 256), dim3(256), 0, sa->stream, (const uint64_t*)b.sp1, b.sp2, b.nw1, b.nw2);
+		/* the bitmaps are the new base's from here on -- if the batch accept goes through, which the status read below says */
+		if (next_gstep != ~0ull && (rc = launch_targets_ahead(sa, next_gstep))) return rc;
 		hipLaunchKernelGGL(k_batch_scan, dim3(1), dim3(1024), 0, sa->stream, sa->batch, sa->ab);
 		hipLaunchKernelGGL(k_batch_fill, dim3(256), dim3(256), 0, sa->stream, sa->batch, sa->ab);
 		hipLaunchKernelGGL(k_batch_chains, dim3(sa->batch.nctx), dim3(MGL_BATCH_THREADS), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
@@ -1401,6 +1434,7 @@ static int launch_bulk_tail(mgl_sa* sa)
 		HIPCHK(hipEventSynchronize(sa->ev_bstat));
 		memcpy(bstat, sa->h_bstat, sizeof bstat);
 		closed = bstat[0] == 3u || bstat[0] == 0u;
+		if (!closed && sa->tgt_ahead) sa->tgt_ahead = 2; /* the step goes to the rebuild (or was never committed): the targets are made again */
 		if (sa->force_batch_fail) {
 			const uint32_t zero = 0u;
 			HIPCHK(hipMemcpy(sa->batch.hdr + 9, &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -1458,6 +1492,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	const int mode = (sa->incremental && sa->parallel_build) ? sa->accept_mode : MGL_ACCEPT_SINGLE; /* bulk steps rebuild with the parallel builder */
 	sa->mode_log.clear();
 	sa->la_ready = false;
+	if (sa->tgt_ahead) sa->tgt_ahead = 2; /* (only behind a run that ended early: whatever was queued is not trusted) */
 	const bool la_ok = sa->la_enabled && inc_apply && sa->split_nbr && sa->ctx.diag_stop == 0;
 	const uint64_t rollbacks_before = sa->bulk_rollbacks;
 	std::vector<uint8_t> sim_timed; /* per timed step: how many of the regular k_sim launches carry events (0: none, the one-kernel form ran) */
@@ -1495,7 +1530,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
 			if (bulk) {
 				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
-				if ((rc = launch_bulk_tail(sa))) return rc;
+				if ((rc = launch_bulk_tail(sa, s + 1 < steps ? before.gstep + s + 1 : ~0ull))) return rc;
 				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
 				continue;
 			}
@@ -1505,7 +1540,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			if (inc_apply) {
 				/* the accept changes the base: the speculative pick + walk of the next step read it until they are through */
 				if (sa->la_ready) for (uint32_t h = 0; h < nbr_slices(sa); h++) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_spec[h], 0));
-				if ((rc = launch_apply(sa))) return rc;
+				if ((rc = launch_apply(sa, s + 1 < steps ? before.gstep + s + 1 : ~0ull))) return rc;
 			} else {
 				hipLaunchKernelGGL(k_copy_best, dim3(256), dim3(256), 0, sa->stream, (const Control*)sa->base.ctl,
 				                   (const mgl_pk*)sa->base.v.slab, sa->d_best, sa->ctx.n);

@@ -1456,6 +1456,7 @@ __global__ void __launch_bounds__(256) k_targets(DevCtx c, const uint64_t* onwal
 	const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	if (j >= K) return;
 	const uint64_t gstep = step_override != ~0ull ? step_override : ctl->gstep;
-	const uint32_t t = stratified_target(onwalk, nw0, c.strat_pre, c.strat_nblk, (uint32_t)ctl->packets, K, j, mgl_rng_draw(mgl_rng_key(seed, gstep, j), 0), lane);
+	/* packets on the walk: the last prefix sum (Control::packets says the same once the accept is through; this kernel may run beside it) */
+	const uint32_t t = stratified_target(onwalk, nw0, c.strat_pre, c.strat_nblk, c.strat_pre[c.strat_nblk], K, j, mgl_rng_draw(mgl_rng_key(seed, gstep, j), 0), lane);
 	if (lane == 0) tgt[j] = t;
 }

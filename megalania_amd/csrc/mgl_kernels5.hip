@@ -36,7 +36,7 @@
  */
 #include "mgl_base2.h"
 
-#define MGL_BATCH_MAX 128u     /* taken neighbours a batch accept handles */
+#define MGL_BATCH_MAX 192u     /* taken neighbours a batch accept handles */
 #define MGL_BATCH_JCAP 512u    /* journal entries per cluster */
 #define MGL_BATCH_EVCAP 4096u  /* inserted / removed events staged per cluster */
 #define MGL_BATCH_OPCAP 2048u  /* bitmap / state-record ops per cluster */

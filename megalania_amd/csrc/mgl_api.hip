@@ -164,6 +164,7 @@ struct mgl_sa {
 	bool count_traffic = false;
 	unsigned long long* d_traffic = nullptr; /* [0] bytes [1] spare */
 	bool la_enabled = false, la_ready = false;
+	uint32_t short_looks = 0;      /* blocks of at most four steps still to come after a switch of the launch form */
 	uint8_t* d_la_mark = nullptr;
 	uint32_t* d_la_list = nullptr;
 	uint32_t* d_la_hdr = nullptr;  /* [0] neighbours to evaluate again, [1] second-pass entries of the speculative launch */
@@ -1508,6 +1509,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		/* AUTO: a block is 16 single / 4 bulk steps wherever the calls' boundaries fall (blk_done steps of it are done) */
 		const uint64_t full = mode == MGL_ACCEPT_AUTO ? (bulk ? 4u : 16u) : 64u;
 		uint64_t block = mode == MGL_ACCEPT_AUTO ? full - sa->blk_done : full;
+		if (sa->short_looks && block > 4u) block = 4u; /* a form was just switched (a trial, usually): look again soon, a trial of a form twice as slow should not last a whole block */
 		if (block > steps - s) block = steps - s;
 		for (uint64_t e = s + block; s < e; s++) {
 			const bool t = s < timed_steps;
@@ -1556,7 +1558,8 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 			Control now;
 			if ((rc = read_ctl(sa, sa->base, &now))) return rc;
 			if (now.error_flags) break;
-			if (sa->adaptive) sa->form_single = now.nbr_single != 0;
+			if (sa->short_looks) sa->short_looks--;
+			if (sa->adaptive && sa->form_single != (now.nbr_single != 0)) { sa->form_single = now.nbr_single != 0; sa->short_looks = 3; }
 			if (block_over) {
 				auto_decide(sa, bulk, full, now.imp_cands - sa->blk_imp0, now.accepted - sa->blk_acc0);
 				sa->blk_done = 0; sa->blk_imp0 = now.imp_cands; sa->blk_acc0 = now.accepted;
@@ -1566,7 +1569,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	HIPCHK(hipEventRecord(sa->ev_end, sa->stream));
 	HIPCHK(hipStreamSynchronize(sa->stream));
 	if ((rc = read_ctl(sa, sa->base, &after))) return rc;
-	if (sa->adaptive) sa->form_single = after.nbr_single != 0;
+	if (sa->adaptive && sa->form_single != (after.nbr_single != 0)) { sa->form_single = after.nbr_single != 0; sa->short_looks = 3; }
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
 		stats->steps = after.gstep - before.gstep;

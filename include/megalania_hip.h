@@ -97,8 +97,9 @@ typedef struct {
 	uint64_t packets;        /* packets on the current slab's walk */
 	uint64_t packets_evaluated; /* sum over evaluations of the packets costed (for B_eval) */
 	double gpu_ms_total;     /* first launch -> last launch, HIP events on the library's stream */
-	double gpu_ms_neighbours;/* sum over launches of the neighbour kernel (MGL_F_TIMING) */
-	double gpu_ms_rebuild;   /* sum over launches of the base rebuild kernel (MGL_F_TIMING) */
+	double gpu_ms_neighbours;/* sum over the timed steps of the neighbour kernels' span (MGL_F_TIMING: every step of a run of at most 16 steps,
+	                          * every fourth step of a longer one, at most 512; `neighbour_launches` says how many were timed) */
+	double gpu_ms_rebuild;   /* the same steps: decision / selection and accept (or rebuild) */
 	uint64_t neighbour_launches;
 	uint64_t full_rebuilds;       /* accepted steps whose base update fell back to a full rebuild */
 	uint64_t fallback_neighbours; /* neighbours costed by the full-walk kernel instead of incrementally */

@@ -1487,7 +1487,10 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 	int rc = read_ctl(sa, sa->base, &before);
 	if (rc) return rc;
 	const bool timing = (sa->cfg.flags & MGL_F_TIMING) != 0;
-	const uint64_t timed_steps = timing ? (steps < 512 ? steps : 512) : 0;
+	/* MGL_F_TIMING brackets steps with events: every step of a short run, every fourth of a longer one (the ten event records of a
+	 * timed step cost it 30 us at 10 MB) */
+	const uint64_t t_stride = steps > 16 ? 4u : 1u;
+	const uint64_t timed_steps = timing ? ((steps + t_stride - 1) / t_stride < 512 ? (steps + t_stride - 1) / t_stride : 512) : 0;
 	const bool inc_apply = sa->incremental && sa->incremental_apply;
 	const DecideArgs dargs = decide_args(sa);
 	const int mode = (sa->incremental && sa->parallel_build) ? sa->accept_mode : MGL_ACCEPT_SINGLE; /* bulk steps rebuild with the parallel builder */
@@ -1512,9 +1515,10 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 		if (sa->short_looks && block > 4u) block = 4u; /* a form was just switched (a trial, usually): look again soon, a trial of a form twice as slow should not last a whole block */
 		if (block > steps - s) block = steps - s;
 		for (uint64_t e = s + block; s < e; s++) {
-			const bool t = s < timed_steps;
+			const bool t = s % t_stride == 0 && s / t_stride < timed_steps;
+			const uint64_t ti = s / t_stride; /* the step's place among the timed ones */
 			if (sa->mode_log.size() < (1u << 20)) sa->mode_log.push_back(bulk ? 1 : 0);
-			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 0), sa->stream));
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * ti + 0), sa->stream));
 			/* look-ahead: this step's pick + walk may have run beside the previous step's tail, into the other buffer set */
 			const bool from_la = sa->la_ready;
 			if (from_la) {
@@ -1523,22 +1527,22 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 				sa->alt = now;
 				sa->la_ready = false;
 			}
-			sa->time_sim_step = (t && sa->split_nbr && !sa->form_single && !from_la) ? (int64_t)s : -1;
-			sim_timed.push_back(sa->time_sim_step >= 0 ? (nbr_slices(sa) < 2u ? 1 : 2) : 0);
+			sa->time_sim_step = (t && sa->split_nbr && !sa->form_single && !from_la) ? (int64_t)ti : -1;
+			if (t) sim_timed.push_back(sa->time_sim_step >= 0 ? (nbr_slices(sa) < 2u ? 1 : 2) : 0);
 			rc = launch_neighbours(sa, ~0ull, (s == 0 && !from_la) || !inc_apply, from_la);
 			sa->time_sim_step = -1;
 			if (rc) return rc;
 			if (la_ok && !bulk && !sa->form_single && s + 1 < e && (rc = launch_lookahead(sa, before.gstep + s + 1, from_la))) return rc;
-			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 1), sa->stream));
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * ti + 1), sa->stream));
 			if (bulk) {
-				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
+				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * ti + 2), sa->stream));
 				if ((rc = launch_bulk_tail(sa, s + 1 < steps ? before.gstep + s + 1 : ~0ull))) return rc;
-				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
+				if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * ti + 3), sa->stream));
 				continue;
 			}
 			hipLaunchKernelGGL(k_decide, dim3(1), dim3(1024), 0, sa->stream, sa->ctx, sa->base.v, sa->base.ctl, sa->nbr, dargs, inc_apply ? 0 : 1);
 			HIPCHK(hipGetLastError());
-			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 2), sa->stream));
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * ti + 2), sa->stream));
 			if (inc_apply) {
 				/* the accept changes the base: the speculative pick + walk of the next step read it until they are through */
 				if (sa->la_ready) for (uint32_t h = 0; h < nbr_slices(sa); h++) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_spec[h], 0));
@@ -1550,7 +1554,7 @@ extern "C" int mgl_sa_run(mgl_sa* sa, uint64_t steps, mgl_sa_stats* stats)
 				if ((rc = rebuild_base(sa, 1))) return rc;
 				if (sa->incremental && sa->snapshots && (rc = launch_snapshot(sa, sa->snap_best, 1, 0, 1))) return rc;
 			}
-			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * s + 3), sa->stream));
+			if (t) HIPCHK(hipEventRecord(pool_event(sa, 4 * ti + 3), sa->stream));
 		}
 		if (mode == MGL_ACCEPT_AUTO) sa->blk_done += block;
 		const bool block_over = mode == MGL_ACCEPT_AUTO && sa->blk_done == full;

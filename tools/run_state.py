@@ -14,7 +14,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 K = int(sys.argv[4]) if len(sys.argv) > 4 else DEFAULT_K[cfg]
 data, desc = corpus.config_input(cfg)
 props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
-sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=len(data), timing=True, **props)
+sa = binding.SA(data, neighbours_per_step=K, seed=1673551, iters_per_epoch=len(data), timing=not os.environ.get("MGL_RUN_NOTIMING"), **props)
 if os.environ.get("MGL_RUN_GREEDY"):  # the state bench.py measures above 32 MB: the greedy seed, no search before the timed steps
     sa.seed_greedy(int(os.environ["MGL_RUN_GREEDY"]))
     sa.set_accept_mode("single")

@@ -481,8 +481,12 @@ def main():
         if counted and sim_ms:
             per_launch = counted["bytes"] / counted["launches"]
             roof["algorithmic_bytes_per_launch"] = per_launch
-            roof["algorithmic_bytes_per_evaluation"] = counted["bytes"] / max(1, counted["evaluations"])
-            roof["counted_over"] = f"{counted['steps']} steps after the timed region ({counted['launches']} launches, kernel's own byte counters on)"
+            # per evaluation: over the steps that ran the split form (k_sim launches per such step: one per slice of the step's
+            # neighbours -- two above 1 MiB -- and one over the second pass's list; steps of a trial of the one-kernel form launch none)
+            per_step = 3 if n > (1 << 20) else 2
+            roof["algorithmic_bytes_per_evaluation"] = per_launch * per_step / max(1.0, counted["evaluations"] / max(1, counted["steps"]))
+            roof["counted_over"] = (f"{counted['launches'] // per_step} of {counted['steps']} steps after the timed region "
+                                    f"({counted['launches']} launches, kernel's own byte counters on)")
             roof["achieved"] = per_launch / (sim_ms * 1e-3) / 1e9
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         nk = {"avg_ms_per_step_live": nbr_ms, "launches_timed": launches}  # all neighbour kernels of a step together

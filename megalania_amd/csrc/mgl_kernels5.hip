@@ -519,22 +519,33 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 				const uint32_t pp[8] = { c_pa.x, c_pa.y, c_pa.z, c_pa.w, c_pb.x, c_pb.y, c_pb.z, c_pb.w };
 				const uint32_t ew[4] = { c_ev.x, c_ev.y, c_ev.z, c_ev.w };
 				const uint32_t e0 = k & 7u;
-				bool done = false;
+				/* nothing the re-join test looks at changes inside the chunk: whether a re-join ends the run is decided once, and the
+				 * eight entries go through without a branch (selects; the stores under their own mask) */
+				const uint32_t nxt_cl = nxt0 == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
+				const bool join_ends = nxt_cl != last_cl;
+				bool live = true;
+				int32_t dc8 = 0;
 #pragma unroll
 				for (uint32_t e = 0; e < 8; e++) {
-					if (e < e0 || done) continue;
 					const uint32_t ev = (ew[e >> 1] >> ((e & 1u) * 16u)) & 0xFFFFu;
 					const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
-					if (p == bp) {
-						const uint32_t nxt_cl = nxt0 == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
-						if (nxt_cl != last_cl) { r.hi = pp[e]; done = true; continue; } /* re-joined: the run ends at old entry k */
+					const bool in = live && e >= e0;
+					const bool stop = in && p == bp && join_ends; /* re-joined: the run ends at old entry k */
+					r.hi = stop ? pp[e] : r.hi;
+					live = live && !stop;
+					const bool take = in && !stop;
+					if (WRITE) { /* (an entry that is not written goes to the spare entry behind the run's place: no branch) */
+						const uint32_t wi = (take && ns < wcap) ? at + ns : at + wcap;
+						span_pos[wi] = pp[e]; span_ev[wi] = (uint16_t)((bb << 15) | p);
 					}
-					if (WRITE && ns < wcap) { span_pos[at + ns] = pp[e]; span_ev[at + ns] = (uint16_t)((bb << 15) | p); }
-					ns++;
-					dc += (long long)T[bb ? 2048u - p : p] - (long long)T[bb ? 2048u - bp : bp];
-					p = mgl_prob_update(p, bb);
-					k++;
+					const int32_t d = (int32_t)T[bb ? 2048u - p : p] - (int32_t)T[bb ? 2048u - bp : bp];
+					dc8 += take ? d : 0;
+					p = take ? mgl_prob_update(p, bb) : p;
+					ns += take ? 1u : 0u;
+					k += take ? 1u : 0u;
 				}
+				dc += dc8;
+				const bool done = !live;
 				if (done) break;
 				continue;
 			}
@@ -660,9 +671,9 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		 * run again in step 5, into a place of its size) ... */
 		const uint32_t res = bt.hdr[1] <= MGL_BATCH_FEW ? MGL_BATCH_RES_FEW : MGL_BATCH_RES;
 		if (tid < ng) {
-			const uint32_t at = atomicAdd(&ab.hdr[6], res);
+			const uint32_t at = atomicAdd(&ab.hdr[6], res + 8u); /* (+ the spare entry the tail loop writes to instead of branching) */
 			s_gat[tid] = at;
-			if (at + res > ab.span_cap) s_fail = 1;
+			if (at + res + 8u > ab.span_cap) s_fail = 1;
 			else s_run[tid] = batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[tid], s_gr[tid], s_gcl, tid, ab.span_pos, ab.span_ev, at, res, sb_row, sb_info);
 		}
 		__syncthreads();
@@ -707,8 +718,8 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 			const uint32_t spn = r0.ns + (r0.uncoupled ? 1u : 0u);
 			uint32_t at = s_hspan[tid];
 			if (at == 0xFFFFFFFFu) {
-				at = atomicAdd(&ab.hdr[6], spn);
-				if (at + spn > ab.span_cap) s_fail = 1;
+				at = atomicAdd(&ab.hdr[6], spn + 1u);
+				if (at + spn + 1u > ab.span_cap) s_fail = 1;
 				else {
 					s_hspan[tid] = at;
 					(void)batch_run<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, at, spn, sb_row, sb_info);

@@ -56,7 +56,7 @@ __device__ __forceinline__ Verdict judge(const DevCtx& c, const Control* ctl, co
 			ok = (cst - base_cost) * 2048u <= t_eff * (uint64_t)c.cost_tbl[u];
 		} else {
 			const uint64_t m = i * i + 1ull + (uint64_t)ctl->phase * a.iters_per_epoch / 2ull;
-			ok = ((uint64_t)draw % m) < a.sqrt_thresh;
+			ok = (m > 0x7FFFFFFFull ? (uint64_t)draw : (uint64_t)draw % m) < a.sqrt_thresh; /* (draws are 31 bits: beyond i = 46 341 the division changes nothing) */
 		}
 	}
 	if (ok) v.key = ((v.improving ? 0ull : 1ull) << 63) | (cst << 20) | j;

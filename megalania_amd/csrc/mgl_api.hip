@@ -660,7 +660,7 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 		BatchBuf& bt = sa->batch;
 		dfree(bt.hdr); dfree(bt.cl); dfree(bt.jpos); dfree(bt.jnew); dfree(bt.jold); dfree(bt.st_ikey); dfree(bt.st_rkey); dfree(bt.st_ipos);
 		dfree(bt.st_rpos); dfree(bt.ops); dfree(bt.ins_cl); dfree(bt.rem_cl); dfree(bt.acc); dfree(bt.runs);
-		dfree(bt.cnt_i); dfree(bt.cnt_r); dfree(bt.off_i); dfree(bt.off_r); dfree(bt.cur_i); dfree(bt.cur_r);
+		dfree(bt.cnt_i); dfree(bt.cnt_r); dfree(bt.off_i); dfree(bt.off_r); dfree(bt.cur_i); dfree(bt.cur_r); dfree(bt.touched);
 		dfree(bt.bk_ipos); dfree(bt.bk_rpos); dfree(bt.bk_ibit); dfree(bt.bk_icl); dfree(bt.bk_rcl);
 	}
 	for (hipEvent_t e : sa->ev_sim_pool) if (e) (void)hipEventDestroy(e);
@@ -975,7 +975,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 			bt.nctx = L.total;
 			bt.runs_cap = 1u << 17;
 			HIPCHK(hipMalloc(&bt.runs, sizeof(uint4) * 2 * (size_t)bt.runs_cap));
-			for (uint32_t** p : { &bt.cnt_i, &bt.cnt_r, &bt.off_i, &bt.off_r, &bt.cur_i, &bt.cur_r }) {
+			for (uint32_t** p : { &bt.cnt_i, &bt.cnt_r, &bt.off_i, &bt.off_r, &bt.cur_i, &bt.cur_r, &bt.touched }) {
 				HIPCHK(hipMalloc(p, sizeof(uint32_t) * (bt.nctx + 64u)));
 				HIPCHK(hipMemset(*p, 0, sizeof(uint32_t) * (bt.nctx + 64u)));
 			}
@@ -1422,7 +1422,7 @@ static int launch_bulk_tail(mgl_sa* sa, uint64_t next_gstep)
 		if (next_gstep != ~0ull && (rc = launch_targets_ahead(sa, next_gstep))) return rc;
 		hipLaunchKernelGGL(k_batch_scan, dim3(1), dim3(1024), 0, sa->stream, sa->batch, sa->ab);
 		hipLaunchKernelGGL(k_batch_fill, dim3(256), dim3(256), 0, sa->stream, sa->batch, sa->ab);
-		hipLaunchKernelGGL(k_batch_chains, dim3(sa->batch.nctx), dim3(MGL_BATCH_THREADS), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
+		hipLaunchKernelGGL(k_batch_chains, dim3(MGL_BATCH_GRID), dim3(MGL_BATCH_THREADS), 0, sa->stream, sa->ctx, b, sa->base.ctl, sa->batch, sa->ab);
 		hipLaunchKernelGGL(k_batch_ckpt, dim3(1024, 8), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->batch, sa->ab);
 		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 0, (const uint32_t*)sa->batch.hdr);
 		hipLaunchKernelGGL(k_apply_jobs, dim3(1024), dim3(256), 0, sa->stream, b, (const Control*)sa->base.ctl, sa->ab, 1, (const uint32_t*)sa->batch.hdr);

@@ -63,6 +63,7 @@ struct BatchBuf {
 	uint32_t* cnt_i; uint32_t* cnt_r;   /* per context: events (counted by k_batch_commit) */
 	uint32_t* off_i; uint32_t* off_r;   /* exclusive scans */
 	uint32_t* cur_i; uint32_t* cur_r;   /* fill cursors */
+	uint32_t* touched;                  /* the contexts that have events (hdr[10] of them), listed by k_batch_scan */
 	uint32_t* bk_ipos; uint16_t* bk_ibit; uint8_t* bk_icl; /* MGL_BATCH_ALLOC each */
 	uint32_t* bk_rpos; uint8_t* bk_rcl;
 	uint32_t nctx;      /* contexts (DevCtx::L.total) */
@@ -404,10 +405,10 @@ __global__ void __launch_bounds__(256) k_batch_commit(DevCtx c, Base2 b, Control
 /* per context: where its events go in the bucketed lists (one workgroup: two exclusive scans over the contexts) */
 __global__ void __launch_bounds__(1024) k_batch_scan(BatchBuf bt, ApplyBuf ab)
 {
-	__shared__ uint32_t s_wi[16], s_wr[16], s_bi, s_br;
+	__shared__ uint32_t s_wi[16], s_wr[16], s_bi, s_br, s_nt;
 	if (bt.hdr[0] != 1u) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-	if (tid == 0) { s_bi = 0; s_br = 0; ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0; } /* + the job / span / scratch cursors of k_apply_jobs' lists */
+	if (tid == 0) { s_bi = 0; s_br = 0; s_nt = 0; ab.hdr[4] = 0; ab.hdr[5] = 0; ab.hdr[6] = 0; ab.hdr[7] = 0; } /* + the job / span / scratch cursors of k_apply_jobs' lists */
 	__syncthreads();
 	for (uint32_t base = 0; base < bt.nctx; base += blockDim.x) {
 		const uint32_t cx = base + tid;
@@ -422,10 +423,12 @@ __global__ void __launch_bounds__(1024) k_batch_scan(BatchBuf bt, ApplyBuf ab)
 		uint32_t bi = s_bi, br = s_br;
 		for (uint32_t w = 0; w < wid; w++) { bi += s_wi[w]; br += s_wr[w]; }
 		if (cx < bt.nctx) { bt.off_i[cx] = bi + ii - vi; bt.off_r[cx] = br + ir - vr; }
+		if (cx < bt.nctx && (vi | vr)) bt.touched[atomicAdd(&s_nt, 1u)] = cx; /* (in any order: k_batch_chains takes a workgroup per entry) */
 		__syncthreads();
 		if (tid == blockDim.x - 1u) { s_bi = bi + ii; s_br = br + ir; }
 		__syncthreads();
 	}
+	if (tid == 0) bt.hdr[10] = s_nt;
 }
 /* every event of the combined lists into its context's bucket */
 __global__ void __launch_bounds__(256) k_batch_fill(BatchBuf bt, ApplyBuf ab)
@@ -446,7 +449,8 @@ __global__ void __launch_bounds__(256) k_batch_fill(BatchBuf bt, ApplyBuf ab)
 }
 
 /* ------------------------------------------------------------------ chains */
-#define MGL_BATCH_THREADS MGL_BATCH_MAX /* one workgroup per touched context; a thread per group */
+#define MGL_BATCH_THREADS 512u /* one workgroup per touched context; a thread per group (at most MGL_BATCH_MAX of them), all of them for the parallel parts */
+#define MGL_BATCH_GRID 2048u
 
 struct RunOut {
 	uint32_t k_start, k_end; /* old entries [k_start, k_end) are replaced */
@@ -611,16 +615,18 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 	__shared__ uint32_t s_ng, s_nh, s_fail, s_scr_base, s_job_b, s_job_c, s_newoff, s_newcap, s_newlen, s_maxd;
 	if (bt.hdr[0] != 1u || bt.hdr[4]) return;
 	if (bt.hdr[9]) { if (blockIdx.x == 0 && threadIdx.x == 0) ctl->apply_failed = 1; return; } /* test hook (mgl_debug_set key 5): give up behind the commit */
-	/* one workgroup per context: most have nothing to do */
-	const uint32_t cx = blockIdx.x;
-	if (cx >= bt.nctx) return;
-	const uint32_t ni = bt.cnt_i[cx], nr = bt.cnt_r[cx];
-	if (ni == 0 && nr == 0) return;
+	/* one workgroup per touched context (k_batch_scan lists them: a tenth of the contexts on a step of fifteen moves), the
+	 * grid strides over the list */
+	const uint32_t ntouched = bt.hdr[10];
+	if (blockIdx.x >= ntouched) return;
 	const uint32_t tid = threadIdx.x;
-	if (ni > MGL_BATCH_SUB || nr > MGL_BATCH_SUB) { if (tid == 0) ctl->apply_failed = 1; return; }
 	for (uint32_t i = tid; i < 256; i += blockDim.x) reinterpret_cast<uint4*>(T)[i] = reinterpret_cast<const uint4*>(c.cost_tbl)[i];
-	long long my_cost = 0; /* thread 0 sums the context's runs */
-	{
+	for (uint32_t w = blockIdx.x; w < ntouched; w += gridDim.x) {
+		const uint32_t cx = bt.touched[w];
+		const uint32_t ni = bt.cnt_i[cx], nr = bt.cnt_r[cx];
+		if (ni > MGL_BATCH_SUB || nr > MGL_BATCH_SUB) { if (tid == 0) ctl->apply_failed = 1; return; }
+		long long my_cost = 0; /* thread 0 sums the context's runs */
+		__syncthreads(); /* (the shared arrays are the previous context's until here) */
 		if (tid == 0) s_fail = 0;
 		/* ---- 1. this context's events, by position (its bucket holds them in any order; positions are distinct within a list) */
 		for (int pass = 0; pass < 2; pass++) {
@@ -828,8 +834,8 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 				bt.runs[2u * at + 1u] = make_uint4(r.ns, r.end_p, 0u, 0u);
 			} else ctl->apply_failed = 1;
 		}
+		if (tid == 0 && my_cost) atomicAdd((unsigned long long*)&bt.acc[0], (unsigned long long)my_cost);
 	}
-	if (tid == 0 && my_cost) atomicAdd((unsigned long long*)&bt.acc[0], (unsigned long long)my_cost);
 }
 
 /* dense checkpoints: along every run, the context's value wherever its trajectory changed (one workgroup per run) */

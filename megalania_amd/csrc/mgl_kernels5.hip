@@ -600,6 +600,119 @@ __device__ __forceinline__ RunOut batch_run(const uint32_t* cpos, const uint16_t
 	return r;
 }
 
+/* The same run by a whole wavefront (k_batch_chains takes this form when a context has few groups: the evolved slab's steps).
+ * Every lane carries the run's state; what a lone lane spends its time on -- the tail, old entries re-priced one after the
+ * other -- goes sixty-four entries at a time: the probability recurrence alone runs through them (every lane keeping the value
+ * in front of its own entry), prices, stores and the re-join test are one entry per lane.  Around the context's changes the
+ * steps are the lone lane's, taken by all lanes alike.  Same results, entry for entry (RunOut, the span entries written). */
+template <bool WRITE>
+__device__ __forceinline__ RunOut batch_run_wave(const uint32_t* cpos, const uint16_t* cev, uint32_t len, const uint16_t* T,
+                                                 const uint32_t* s_ipos, const uint16_t* s_ibit, const uint8_t* s_icl, uint32_t ni,
+                                                 const uint32_t* s_rpos, const uint8_t* s_rcl, uint32_t nr,
+                                                 uint32_t ii, uint32_t ri, const uint8_t* s_gcl, uint32_t g,
+                                                 uint32_t* span_pos, uint16_t* span_ev, uint32_t at, uint32_t wcap,
+                                                 const uint32_t* sb_row, uint32_t sb_row_info, uint32_t lane)
+{
+	RunOut r;
+	uint32_t ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF, rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
+	const uint32_t x0 = ipos < rpos ? ipos : rpos;
+	uint32_t k;
+	{
+		const uint32_t nsb = sb_row_info & 0xFFFFFFu, shift = sb_row_info >> 24;
+		uint32_t blk = x0 >> shift;
+		if (blk >= nsb) blk = nsb - 1u;
+		k = uni(chain_lower_bound(cpos, sb_row[blk + 1u], x0, nullptr, sb_row[blk]));
+	}
+	r.k_start = k; r.lo = x0; r.uncoupled = 0; r.hi = MGL_POS_INF;
+	/* sixty-four chain entries, one per lane (entry `len` is the sentinel: position = infinity; nothing is read behind it) */
+	uint32_t wbase = 0xFFFFFFFFu, my_pos = MGL_POS_INF, my_ev = 0;
+	auto window = [&](uint32_t kk) {
+		if (wbase != 0xFFFFFFFFu && kk >= wbase && kk - wbase < 64u) return;
+		wbase = kk;
+		const uint32_t idx = kk + lane;
+		my_pos = idx <= len ? cpos[idx] : MGL_POS_INF;
+		my_ev = idx <= len ? (uint32_t)cev[idx] : 0u;
+	};
+	window(k);
+	uint32_t p = rdlane(my_ev, 0) & 0x7FFu;
+	uint32_t last_cl = s_gcl[g];
+	long long dc_lane = 0, dc_all = 0; /* per lane (the tail's entries) / the same on every lane (the steps around the changes) */
+	uint32_t ns = 0;
+	for (;;) {
+		window(k);
+		const uint32_t off = uni(k - wbase);
+		const uint32_t nxt0 = ipos < rpos ? ipos : rpos;
+		/* the entries from k on that lie in front of the context's next change and of the sentinel: the tail's next stretch */
+		const unsigned long long okm = __ballot(lane >= off && wbase + lane < len && my_pos < nxt0) >> off;
+		const uint32_t cnt = okm == ~0ull ? 64u - off : (uint32_t)__ffsll((long long)~okm) - 1u;
+		if (cnt > 0u) {
+			const uint32_t nxt_cl = nxt0 == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
+			const bool join_ends = nxt_cl != last_cl;
+			const unsigned long long bits = __ballot((my_ev >> 15) != 0u) >> off;
+			uint32_t q = p, mine = 0;
+			for (uint32_t e = 0; e < cnt; e++) { /* the recurrence, alone */
+				mine = lane == off + e ? q : mine;
+				q = mgl_prob_update(q, (uint32_t)((bits >> e) & 1ull));
+			}
+			const uint32_t bp = my_ev & 0x7FFu, bb = my_ev >> 15;
+			const bool in = lane >= off && lane < off + cnt;
+			const unsigned long long eqm = __ballot(in && mine == bp);
+			uint32_t take = cnt;
+			bool done = false;
+			if (eqm != 0ull && join_ends) { /* re-joined: the run ends at the first such entry (which stays as it is) */
+				const uint32_t f = (uint32_t)__ffsll((long long)eqm) - 1u;
+				take = f - off; r.hi = rdlane(my_pos, f); q = rdlane(mine, f); done = true;
+			}
+			if (lane >= off && lane < off + take) {
+				const uint32_t e = lane - off;
+				if (WRITE && ns + e < wcap) { span_pos[at + ns + e] = my_pos; span_ev[at + ns + e] = (uint16_t)((bb << 15) | mine); }
+				dc_lane += (long long)T[bb ? 2048u - mine : mine] - (long long)T[bb ? 2048u - bp : bp];
+			}
+			ns += take; k += take; p = q;
+			if (done) break;
+			continue;
+		}
+		const uint32_t bpos = k > len ? MGL_POS_INF : rdlane(my_pos, off);
+		if (ipos < bpos) { /* an inserted event comes first */
+			const uint32_t bit = s_ibit[ii];
+			last_cl = s_icl[ii];
+			if (WRITE && lane == 0 && ns < wcap) { span_pos[at + ns] = ipos; span_ev[at + ns] = (uint16_t)((bit << 15) | p); }
+			ns++;
+			dc_all += T[bit ? 2048u - p : p];
+			p = mgl_prob_update(p, bit);
+			ii++;
+			ipos = ii < ni ? s_ipos[ii] : MGL_POS_INF;
+			continue;
+		}
+		if (bpos == MGL_POS_INF) { r.uncoupled = 1; break; } /* the sentinel: the final probability changes */
+		const uint32_t ev = rdlane(my_ev, off);
+		const uint32_t bp = ev & 0x7FFu, bb = ev >> 15;
+		const uint32_t nxt = ipos < rpos ? ipos : rpos;
+		if (p == bp && nxt > bpos) {
+			const uint32_t nxt_cl = nxt == MGL_POS_INF ? 0xFFFFu : (ipos <= rpos ? (uint32_t)s_icl[ii] : (uint32_t)s_rcl[ri]);
+			if (nxt_cl != last_cl) { r.hi = bpos; break; }
+		}
+		dc_all -= T[bb ? 2048u - bp : bp];
+		if (rpos == bpos) { /* the old entry goes away */
+			last_cl = s_rcl[ri];
+			ri++;
+			rpos = ri < nr ? s_rpos[ri] : MGL_POS_INF;
+		} else { /* it stays, priced at the new probability */
+			if (WRITE && lane == 0 && ns < wcap) { span_pos[at + ns] = bpos; span_ev[at + ns] = (uint16_t)((bb << 15) | p); }
+			ns++;
+			dc_all += T[bb ? 2048u - p : p];
+			p = mgl_prob_update(p, bb);
+		}
+		k++;
+	}
+	r.k_end = k; r.ns = ns; r.end_p = p;
+	r.dcost = (long long)wave_sum64((uint64_t)dc_lane) + dc_all;
+	uint32_t lg = g;
+	while (s_gcl[lg] != last_cl) lg++;
+	r.last_group = lg;
+	return r;
+}
+
 __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Base2 b, Control* ctl, BatchBuf bt, ApplyBuf ab)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t T[2048];
@@ -676,7 +789,20 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		 * (most runs fit: a perturbed probability re-joins the old trajectory after about a hundred events; one that does not is
 		 * run again in step 5, into a place of its size) ... */
 		const uint32_t res = bt.hdr[1] <= MGL_BATCH_FEW ? MGL_BATCH_RES_FEW : MGL_BATCH_RES;
-		if (tid < ng) {
+		/* few groups: a wavefront per run (batch_run_wave); many: a lane per run, all of them side by side */
+		const uint32_t lane = tid & 63u, wid = tid >> 6, nwaves = blockDim.x >> 6;
+		const bool by_wave = ng <= 3u * nwaves;
+		if (by_wave) {
+			for (uint32_t g = wid; g < ng; g += nwaves) {
+				uint32_t at = 0;
+				if (lane == 0) at = atomicAdd(&ab.hdr[6], res + 8u);
+				at = uni(at);
+				if (lane == 0) s_gat[g] = at;
+				if (at + res + 8u > ab.span_cap) { s_fail = 1; continue; }
+				const RunOut rr = batch_run_wave<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, at, res, sb_row, sb_info, lane);
+				if (lane == 0) s_run[g] = rr;
+			}
+		} else if (tid < ng) {
 			const uint32_t at = atomicAdd(&ab.hdr[6], res + 8u); /* (+ the spare entry the tail loop writes to instead of branching) */
 			s_gat[tid] = at;
 			if (at + res + 8u > ab.span_cap) s_fail = 1;
@@ -718,7 +844,23 @@ __global__ void __launch_bounds__(MGL_BATCH_THREADS) k_batch_chains(DevCtx c, Ba
 		const bool moved = noff != off;
 		/* ---- 5. a run that counts and did not fit its place: again, into one of its size; the new sentinel behind a run that
 		 * ran into the old one un-coupled */
-		if (tid < nh) {
+		if (by_wave) {
+			for (uint32_t h = wid; h < nh; h += nwaves) {
+				const uint32_t g = s_hlist[h];
+				const RunOut r0 = s_run[g];
+				const uint32_t spn = r0.ns + (r0.uncoupled ? 1u : 0u);
+				uint32_t at = s_hspan[h];
+				if (at == 0xFFFFFFFFu) {
+					at = 0;
+					if (lane == 0) at = atomicAdd(&ab.hdr[6], spn + 1u);
+					at = uni(at);
+					if (at + spn + 1u > ab.span_cap) { s_fail = 1; continue; }
+					if (lane == 0) s_hspan[h] = at;
+					(void)batch_run_wave<true>(cpos, cev, len, T, s_ipos, s_ibit, s_icl, ni, s_rpos, s_rcl, nr, s_gi[g], s_gr[g], s_gcl, g, ab.span_pos, ab.span_ev, at, spn, sb_row, sb_info, lane);
+				}
+				if (lane == 0 && r0.uncoupled) { ab.span_pos[at + r0.ns] = MGL_POS_INF; ab.span_ev[at + r0.ns] = (uint16_t)r0.end_p; }
+			}
+		} else if (tid < nh) {
 			const uint32_t g = s_hlist[tid];
 			const RunOut& r0 = s_run[g];
 			const uint32_t spn = r0.ns + (r0.uncoupled ? 1u : 0u);

@@ -1001,7 +1001,11 @@ __global__ void __launch_bounds__(256) k_batch_ckpt(Base2 b, const Control* ctl,
 		/* blockIdx.y: the run's rows in gridDim.y slices (a run of a rare context reaches over thousands of rows) */
 		const uint32_t per = (ck_hi - ck_lo + gridDim.y - 1u) / gridDim.y;
 		const uint32_t my_lo = ck_lo + blockIdx.y * per, my_hi = (my_lo + per) < ck_hi ? (my_lo + per) : ck_hi;
+		/* a run that never re-joined reaches to the end of the file: behind its last new entry every row -- whatever its
+		 * boundary -- holds the run's final probability (most of such a run's rows: no boundary search for them) */
+		const uint32_t last_pos = hi == MGL_POS_INF ? (ns ? ab.span_pos[first + ns - 1u] : lo) : MGL_POS_INF;
 		for (uint32_t ck = my_lo + threadIdx.x; ck < my_hi; ck += blockDim.x) {
+			if ((ck << MGL_CK2_SHIFT) > last_pos && last_pos != MGL_POS_INF) { b.ck_probs[(size_t)ck * b.ck_elems + cx] = (uint16_t)end_p; continue; }
 			const uint32_t P = ckpt_boundary(b, ck); /* on the NEW walk (the bitmaps are committed); MGL_POS_INF: the final model */
 			if (P <= lo || P > hi) continue;      /* the value there is the old one */
 			/* probability before the first new entry of the run at or after P */

@@ -418,7 +418,8 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 		}
 		__syncthreads();
 		APPLY_STAGE(1)
-		if (tid == 0) {
+		if (wid == 0) { /* the first wavefront, every lane with the same state (shared-memory writes are the same value from every lane);
+		                 * the tail -- old entries re-priced until the probability re-joins -- sixty-four entries at a time */
 			const uint32_t ni = s_ni, nr = s_nr;
 			uint32_t ii = 0, ri = 0, ns = 0, np = 0, nseg = 0;
 			const uint32_t k0 = k0c;
@@ -443,21 +444,31 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 					bool moved_on = false;
 					for (;;) {
 						const uint32_t rel = k - k0;
-						if (rel + 4u > MGL_APPLY_WIN || ns + 4u > MGL_SPAN_CAP) break;
-						const uint32_t q0 = s_win_pos[rel], q1 = s_win_pos[rel + 1], q2 = s_win_pos[rel + 2], q3 = s_win_pos[rel + 3];
-						const uint32_t e0 = s_win_ev[rel], e1 = s_win_ev[rel + 1], e2 = s_win_ev[rel + 2], e3 = s_win_ev[rel + 3];
-						uint32_t took = 0;
-#define APPLY_FOLLOW(q_, e_) \
-						if (took == 4u || (q_) == MGL_POS_INF || p == ((e_) & 0x7FFu)) { if (took != 4u) took |= 8u; } \
-						else { s_span_pos[ns] = (q_); s_span_ev[ns] = (uint16_t)(((e_) & 0x8000u) | p); ns++; p = mgl_prob_update(p, (e_) >> 15); took++; }
-						APPLY_FOLLOW(q0, e0)
-						if (!(took & 8u)) { APPLY_FOLLOW(q1, e1) }
-						if (!(took & 8u)) { APPLY_FOLLOW(q2, e2) }
-						if (!(took & 8u)) { APPLY_FOLLOW(q3, e3) }
-#undef APPLY_FOLLOW
-						k += took & 7u;
-						moved_on = moved_on || (took & 7u) != 0;
-						if (took & 8u) break; /* sentinel or re-coupled at entry k: the general code below closes up */
+						if (rel >= MGL_APPLY_WIN || ns >= MGL_SPAN_CAP) break;
+						uint32_t avail = MGL_APPLY_WIN - rel;
+						avail = avail < MGL_SPAN_CAP - ns ? avail : MGL_SPAN_CAP - ns;
+						avail = avail < 64u ? avail : 64u;
+						const uint32_t my_pos = lane < avail ? s_win_pos[rel + lane] : MGL_POS_INF;
+						const uint32_t my_ev = lane < avail ? (uint32_t)s_win_ev[rel + lane] : 0u;
+						const unsigned long long okm = __ballot(my_pos != MGL_POS_INF); /* entries in front of the sentinel */
+						const uint32_t cnt = okm == ~0ull ? 64u : (uint32_t)__ffsll((long long)~okm) - 1u;
+						if (cnt == 0u) break; /* the sentinel (or the end of what is staged): the general code below closes up */
+						const unsigned long long bits = __ballot((my_ev >> 15) != 0u);
+						uint32_t q = p, mine = 0;
+						for (uint32_t e = 0; e < cnt; e++) { /* the recurrence alone; every lane keeps the value in front of its entry */
+							mine = lane == e ? q : mine;
+							q = mgl_prob_update(q, (uint32_t)((bits >> e) & 1ull));
+						}
+						const unsigned long long eqm = __ballot(lane < cnt && mine == (my_ev & 0x7FFu));
+						uint32_t take = cnt;
+						if (eqm != 0ull) { /* re-coupled at that entry (which stays) */
+							const uint32_t f = (uint32_t)__ffsll((long long)eqm) - 1u;
+							take = f; q = rdlane(mine, f);
+						}
+						if (lane < take) { s_span_pos[ns + lane] = my_pos; s_span_ev[ns + lane] = (uint16_t)((my_ev & 0x8000u) | mine); }
+						ns += take; k += take; p = q;
+						moved_on = moved_on || take != 0u;
+						if (eqm != 0ull || cnt < avail) break;
 					}
 					if (moved_on) {
 						bpos = CPOS(k); ev = CEV(k);
@@ -524,7 +535,9 @@ __global__ void __launch_bounds__(1024) k_apply_chains(DevCtx c, Base2 b, Contro
 			if (!fail && newlen + 1 > cap) {
 				/* the chain outgrew its slot: move it to fresh space at the top of the pool */
 				newcap = (2u * (newlen + 1u) + 256u + 7u) & ~7u;
-				newoff = atomicAdd(b.pool_top, newcap);
+				newoff = 0;
+				if (lane == 0) newoff = atomicAdd(b.pool_top, newcap);
+				newoff = uni(newoff);
 				if (newoff + newcap > b.pool_cap) fail = true; /* pool exhausted: k_build compacts */
 			}
 			s_newoff = newoff; s_newcap = newcap;

@@ -164,6 +164,7 @@ struct mgl_sa {
 	bool count_traffic = false;
 	unsigned long long* d_traffic = nullptr; /* [0] bytes [1] spare */
 	bool la_enabled = false, la_ready = false;
+	hipGraph_t nbr_graph = nullptr; hipGraphExec_t nbr_graph_exec = nullptr; uint64_t nbr_graph_key = 0; bool graph_ok = false; /* a step's neighbour launches, captured */
 	uint32_t short_looks = 0;      /* blocks of at most four steps still to come after a switch of the launch form */
 	uint8_t* d_la_mark = nullptr;
 	uint32_t* d_la_list = nullptr;
@@ -461,23 +462,12 @@ static int launch_targets_ahead(mgl_sa* sa, uint64_t next_gstep)
 	sa->tgt_ahead = 1;
 	return MGL_OK;
 }
-static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_counts = true, bool from_lookahead = false)
+static uint64_t graph_key(const mgl_sa* sa);
+/* the launches of a step's neighbour evaluation on the incremental engine: pick / walk slices on two streams, re-simulations on a
+ * third, second pass, last resort (what launch_neighbours queues behind its targets) */
+static int launch_neighbours_body(mgl_sa* sa, uint64_t step_override, bool from_lookahead)
 {
 	const uint32_t K = sa->cfg.neighbours_per_step;
-	if (sa->d_strat_pre) {
-		if (sa->tgt_ahead) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_tgt, 0)); /* made beside the previous step's accept (or at least out of the buffers' way) */
-		if (sa->tgt_ahead != 1) launch_targets(sa, sa->stream, step_override);
-		sa->tgt_ahead = 0;
-	}
-	if (!sa->incremental) {
-		const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
-		hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
-		                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
-		                   (const uint32_t*)nullptr, (const uint32_t*)nullptr); NBR_TRACE("k_neighbours");
-		HIPCHK(hipGetLastError());
-		return MGL_OK;
-	}
-	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 8 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
 	const uint32_t blocks2 = (K + sa->waves_per_block2 - 1) / sa->waves_per_block2;
 	const bool split_now = sa->split_nbr && !sa->form_single;
 	const uint32_t sim_lds_regular = ((((sa->ctx.L.total + 31u) >> 5) + 3u) & ~3u) * 4u + sa->chg_cap * 16u;
@@ -603,6 +593,59 @@ static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_count
 	return MGL_OK;
 }
 
+static int launch_neighbours(mgl_sa* sa, uint64_t step_override, bool zero_counts = true, bool from_lookahead = false)
+{
+	const uint32_t K = sa->cfg.neighbours_per_step;
+	if (sa->d_strat_pre) {
+		if (sa->tgt_ahead) HIPCHK(hipStreamWaitEvent(sa->stream, sa->ev_tgt, 0)); /* made beside the previous step's accept (or at least out of the buffers' way) */
+		if (sa->tgt_ahead != 1) launch_targets(sa, sa->stream, step_override);
+		sa->tgt_ahead = 0;
+	}
+	if (!sa->incremental) {
+		const uint32_t blocks = (K + sa->waves_per_block - 1) / sa->waves_per_block;
+		hipLaunchKernelGGL(k_neighbours, dim3(blocks), dim3(64 * sa->waves_per_block), sa->nbr_lds, sa->stream, sa->ctx, sa->base.v,
+		                   (const Control*)sa->base.ctl, sa->cfg.seed, step_override, K, sa->nbr, sa->per_wave_bytes,
+		                   (const uint32_t*)nullptr, (const uint32_t*)nullptr); NBR_TRACE("k_neighbours");
+		HIPCHK(hipGetLastError());
+		return MGL_OK;
+	}
+	if (zero_counts) HIPCHK(hipMemsetAsync(sa->d_counts, 0, 8 * sizeof(uint32_t), sa->stream)); /* todo counts + spill slots; k_step_end clears them between steps */
+	/* The launches of a step are the same from step to step (the kernels read the step's number from the control block): captured
+	 * once as a graph -- three streams, their events -- and replayed, unless something about them changed (the launch form, a
+	 * buffer, a diagnostic) or the step is a timed or traced one. */
+	if (sa->graph_ok && step_override == ~0ull && !from_lookahead && !sa->la_enabled && sa->time_sim_step < 0 && !sa->count_traffic && !g_trace && !g_prof_big && sa->d_prof == nullptr) {
+		const uint64_t key = graph_key(sa);
+		if (sa->nbr_graph_exec == nullptr || key != sa->nbr_graph_key) {
+			if (sa->nbr_graph_exec) { (void)hipGraphExecDestroy(sa->nbr_graph_exec); sa->nbr_graph_exec = nullptr; }
+			if (sa->nbr_graph) { (void)hipGraphDestroy(sa->nbr_graph); sa->nbr_graph = nullptr; }
+			HIPCHK(hipStreamBeginCapture(sa->stream, hipStreamCaptureModeRelaxed));
+			const int rc = launch_neighbours_body(sa, ~0ull, false);
+			const hipError_t ec = hipStreamEndCapture(sa->stream, &sa->nbr_graph);
+			if (rc) return rc;
+			if (ec != hipSuccess || sa->nbr_graph == nullptr) return fail(MGL_EDEVICE, "launch_neighbours: graph capture failed");
+			HIPCHK(hipGraphInstantiate(&sa->nbr_graph_exec, sa->nbr_graph, nullptr, nullptr, 0));
+			sa->nbr_graph_key = key;
+		}
+		HIPCHK(hipGraphLaunch(sa->nbr_graph_exec, sa->stream));
+		return MGL_OK;
+	}
+	return launch_neighbours_body(sa, step_override, from_lookahead);
+}
+
+/* everything a step's neighbour launches are made of: a captured graph is good while this stays what it was */
+static uint64_t graph_key(const mgl_sa* sa)
+{
+	uint64_t h = 1469598103934665603ull;
+	auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } };
+	mix(&sa->ctx, sizeof sa->ctx); mix(&sa->b2, sizeof sa->b2); mix(&sa->base, sizeof sa->base); mix(&sa->nbr, sizeof sa->nbr); mix(&sa->big, sizeof sa->big);
+	const uint64_t w[] = { sa->cfg.neighbours_per_step, sa->cfg.seed, (uint64_t)sa->form_single, (uint64_t)sa->split_nbr, sa->halves, sa->waves_per_block, sa->waves_per_block2,
+	                       sa->pick_waves, sa->per_wave_pick, sa->per_wave_rest, sa->per_wave2, sa->per_wave_bytes, sa->nbr_lds, sa->nbr2_lds, sa->chg_cap, sa->sim_waves,
+	                       (uint64_t)(uintptr_t)sa->d_todo, (uint64_t)(uintptr_t)sa->d_todo2, (uint64_t)(uintptr_t)sa->d_todo3, (uint64_t)(uintptr_t)sa->d_counts,
+	                       (uint64_t)(uintptr_t)sa->d_pickrec, (uint64_t)(uintptr_t)sa->d_pickstate, (uint64_t)g_big_inline_sim };
+	mix(w, sizeof w);
+	return h;
+}
+
 static int import_slab(mgl_sa* sa, const mgl_packet* packets, mgl_pk* d_slab)
 {
 	HIPCHK(hipMemcpyAsync(sa->d_aos, packets, sizeof(mgl_packet) * (size_t)sa->n, hipMemcpyHostToDevice, sa->stream));
@@ -677,6 +720,8 @@ extern "C" void mgl_sa_destroy(mgl_sa* sa)
 	for (auto& e : sa->ev_rest) if (e) (void)hipEventDestroy(e);
 	if (sa->ev_sim) (void)hipEventDestroy(sa->ev_sim);
 	if (sa->ev_val) (void)hipEventDestroy(sa->ev_val);
+	if (sa->nbr_graph_exec) (void)hipGraphExecDestroy(sa->nbr_graph_exec);
+	if (sa->nbr_graph) (void)hipGraphDestroy(sa->nbr_graph);
 	if (sa->ev_fork) (void)hipEventDestroy(sa->ev_fork);
 	if (sa->ev_tgt) (void)hipEventDestroy(sa->ev_tgt);
 	if (sa->ev_tgt_go) (void)hipEventDestroy(sa->ev_tgt_go);
@@ -699,6 +744,7 @@ static int create_impl(mgl_sa* sa, const uint8_t* data, size_t n)
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_sim, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&sa->ev_val, hipEventDisableTiming));
 	/* measured: + 8 % on the 10 MB input, nothing on the 100 KB one (its kernels are too short to overlap) */
+	sa->graph_ok = getenv("MGL_GRAPH") != nullptr;
 	sa->halves = getenv("MGL_HALVES") ? (uint32_t)atoi(getenv("MGL_HALVES")) : (n > (1u << 20) ? 2u : 1u);
 	if (sa->halves < 1 || sa->halves > 8) sa->halves = 1;
 	HIPCHK(hipEventCreate(&sa->ev_begin));

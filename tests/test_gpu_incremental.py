@@ -375,6 +375,32 @@ def test_parallel_build_serial_segment_path():
     a.close()
 
 
+def test_graph_replay_gives_the_same_trajectory(monkeypatch):
+    """MGL_GRAPH=1 (opt-in): a step's neighbour launches -- three streams, their events -- are captured once as a HIP graph
+    and replayed while nothing about them changes (launch form, buffers): same trajectory as the eager launches, in single
+    and in bulk steps, through switches of the launch form (c2's early repair bursts) and across mgl_sa_run calls."""
+    data, _ = corpus.config_input("c2")
+    K = 4096
+    monkeypatch.delenv("MGL_GRAPH", raising=False)
+    eager = binding.SA(data, accept="auto", neighbours_per_step=K, seed=31)
+    monkeypatch.setenv("MGL_GRAPH", "1")
+    graph = binding.SA(data, accept="auto", neighbours_per_step=K, seed=31)
+    monkeypatch.delenv("MGL_GRAPH")
+    for chunk in (1, 7, 40, 64, 3, 90):
+        a, b = eager.run(chunk), graph.run(chunk)
+        for k in ("evaluations", "accepted", "current_cost", "best_cost", "packets", "failed", "bulk_steps"):
+            assert a[k] == b[k], (chunk, k)
+    for x in (eager, graph):
+        x.set_accept_mode("single")
+    for chunk in (5, 70, 20):
+        a, b = eager.run(chunk), graph.run(chunk)
+        for k in ("evaluations", "accepted", "current_cost", "best_cost", "packets", "failed"):
+            assert a[k] == b[k], (chunk, k)
+    ca, cb = eager.current(), graph.current()
+    assert ca[1] == cb[1] and (ca[0] == cb[0]).all()
+    eager.close(); graph.close()
+
+
 def test_launch_forms_give_one_trajectory(monkeypatch):
     """The neighbour evaluation runs as two launches (pick + rest, with a second pass), as one kernel,
     or switches between them on the device (k_step_end): same costs for every neighbour, same

@@ -8,7 +8,8 @@ from megalania_amd import binding, corpus
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 K = {"c1": 1024, "c2": 4096, "c3": 16384, "c4": 16384, "c5": 4096}[cfg]
 data, desc = corpus.config_input(cfg)
-sa = binding.SA(data, neighbours_per_step=K, timing=True, iters_per_epoch=len(data), flags=binding.F_PROFILE)
+props = dict(pb=2, max_bucket_scan=4096) if cfg == "c5" else {}
+sa = binding.SA(data, neighbours_per_step=K, timing=True, iters_per_epoch=len(data), flags=binding.F_PROFILE, **props)
 done = 0
 while done < 6000:
     p = sa.run(128); done += p["steps"]

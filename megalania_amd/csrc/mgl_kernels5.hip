@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_batch_fill(BatchBuf bt, ApplyBuf ab)
 }
 
 /* ------------------------------------------------------------------ chains */
-#define MGL_BATCH_THREADS 512u /* one workgroup per touched context; a thread per group (at most MGL_BATCH_MAX of them), all of them for the parallel parts */
+#define MGL_BATCH_THREADS 1024u /* one workgroup per touched context; a thread per group (at most MGL_BATCH_MAX of them), all of them for the parallel parts */
 #define MGL_BATCH_GRID 2048u
 
 struct RunOut {
